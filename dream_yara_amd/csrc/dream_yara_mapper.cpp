@@ -1,0 +1,224 @@
+// dream_yara_mapper — drop-in command line for the reference's mapper (reference src/d_mapper.cpp:114-394,554-585),
+// written against the C ABI of libdyhip (include/dyhip.h) exactly like a maintainer's binding would be.
+// Host work here is I/O only: option parsing, FASTA/FASTQ batches in, SAM text out (reference src/mapper_writer.h).
+#include "../../include/dyhip.h"
+#include "host_formats.hpp"
+#include <iostream>
+#include <fstream>
+#include <sstream>
+#include <algorithm>
+#include <chrono>
+
+using namespace dy;
+
+namespace {
+
+struct CliOptions
+{
+    std::string indicesDir, readsFile, outputFile, filterFile, filterType = "bloom", readGroup = "none";
+    dy_params params;
+    unsigned readsBatch = 100000;
+    bool verbose = false, skipSamHeader = false;
+    std::string commandLine;
+};
+
+[[noreturn]] void fail(const std::string & msg) { throw std::runtime_error(msg); }
+
+void check(int rc) { if (rc != DY_OK) fail(dy_last_error()); }
+
+CliOptions parse(int argc, char ** argv)
+{
+    CliOptions o;
+    dy_params_default(&o.params);
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i)
+    {
+        std::string a = argv[i];
+        auto value = [&]() -> std::string { if (i + 1 >= argc) fail("option requires an argument: " + a); return argv[++i]; };
+        auto uintValue = [&](unsigned lo, unsigned hi) -> unsigned {
+            std::string v = value(); size_t used = 0; unsigned long x = 0;
+            try { x = std::stoul(v, &used); } catch (...) { used = 0; }
+            if (used != v.size() || x < lo || x > hi) fail("the given value '" + v + "' for option " + a + " is out of range");
+            return (unsigned)x;
+        };
+        if (a == "-e" || a == "--error-rate") o.params.error_rate = (float)(uintValue(0, 10) / 100.0);          // src/d_mapper.cpp:339-342
+        else if (a == "-s" || a == "--strata-rate") o.params.strata_rate = (float)(uintValue(0, 10) / 100.0);   // :344-346
+        else if (a == "-y" || a == "--sensitivity")
+        {
+            std::string v = value();
+            if (v == "low") o.params.sensitivity = 0; else if (v == "high") o.params.sensitivity = 1; else if (v == "full") o.params.sensitivity = 2;
+            else fail("the given value '" + v + "' is not in the list of allowed values for sensitivity");
+        }
+        else if (a == "-fi" || a == "--bloom-filter") o.filterFile = value();
+        else if (a == "-ft" || a == "--filter-type")
+        {
+            o.filterType = value();
+            if (o.filterType != "bloom" && o.filterType != "none" && o.filterType != "kmer_direct") fail("unknown filter type " + o.filterType);
+        }
+        else if (a == "-o" || a == "--output-file") o.outputFile = value();
+        else if (a == "-rg" || a == "--read-group") o.readGroup = value();
+        else if (a == "-sm" || a == "--secondary-matches") value();      // read under a legacy name by the reference: no effect (:320)
+        else if (a == "-t" || a == "--threads") uintValue(1, 2048);      // the device replaces the thread pool
+        else if (a == "-rb" || a == "--reads-batch") o.readsBatch = uintValue(1000, 5000000);
+        else if (a == "-sk" || a == "--skip-sam-headers") o.skipSamHeader = true;
+        else if (a == "-v" || a == "--verbose" || a == "-vv" || a == "--very-verbose") o.verbose = true;
+        else if (a.size() > 1 && a[0] == '-') fail("unknown option " + a);
+        else pos.push_back(a);
+    }
+    if (pos.size() < 2) fail("usage: dream_yara_mapper [OPTIONS] <INDEX DIR> <READS>");
+    if (pos.size() > 2) fail("paired-end mapping is not implemented (DY_EUNSUPPORTED)");
+    o.indicesDir = pos[0]; o.readsFile = pos[1];
+    if (o.indicesDir.empty() || o.indicesDir.back() != '/') o.indicesDir += '/';                                // appendTrailingSlash :280
+    if (o.filterFile.empty()) o.filterFile = o.indicesDir + "bloom.filter";                                     // :371-375
+    if (o.readsBatch > 2097151) o.readsBatch = 2097151;
+    for (int i = 0; i < argc; ++i) { if (i) o.commandLine += ' '; o.commandLine += argv[i]; }
+    return o;
+}
+
+void appendUint(std::string & s, unsigned long long v) { char buf[24]; int n = snprintf(buf, sizeof buf, "%llu", v); s.append(buf, (size_t)n); }
+
+} // namespace
+
+int main(int argc, char ** argv)
+{
+    try
+    {
+        CliOptions opt = parse(argc, argv);
+        if (opt.filterType == "kmer_direct") fail("filter type kmer_direct is not implemented (DY_EUNSUPPORTED)");
+        auto t0 = std::chrono::steady_clock::now();
+        dy_ctx * ctx = nullptr; check(dy_ctx_create(0, &ctx));
+        dy_ibf * ibf = nullptr;
+        uint32_t nBins = 0;
+        if (opt.filterType == "bloom")
+        {
+            check(dy_ibf_load(ctx, opt.filterFile.c_str(), &ibf));
+            dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
+            nBins = info.n_bins;                                                                                // readFilterMetadata :532-548
+        }
+        else
+        {
+            opt.params.use_filter = 0;
+            for (;; ++nBins) { std::ifstream f(opt.indicesDir + std::to_string(nBins) + ".txt.size"); if (!f) break; }
+            if (!nBins) fail("Error while opening reference file.");
+        }
+        dy_index * idx = nullptr; check(dy_index_load(ctx, opt.indicesDir.c_str(), nBins, &idx));
+        auto t1 = std::chrono::steady_clock::now();
+
+        std::ofstream ofs;
+        if (!opt.outputFile.empty()) { ofs.open(opt.outputFile); if (!ofs) fail("Error while opening output file."); }
+        std::ostream & os = opt.outputFile.empty() ? std::cout : ofs;
+        if (!opt.skipSamHeader)
+        {   // fillHeader, reference src/mapper_writer.h:124-155; order as in the gold files
+            os << "@HD\tVN:1.4\tSO:unsorted\n";
+            os << "@PG\tID:Yara\tPN:Yara\tVN:1.0.2 []\tCL:" << opt.commandLine << "\n";
+            os << "@RG\tID:" << opt.readGroup << "\tSM:" << opt.readGroup << "\tPG:Yara\n";
+            for (uint32_t c = 0; c < dy_index_contigs(idx); ++c)
+                os << "@SQ\tSN:" << dy_index_contig_name(idx, c) << "\tLN:" << dy_index_contig_length(idx, c) << "\n";
+        }
+
+        ReadsFile in(opt.readsFile);
+        ReadsBatch batch;
+        unsigned long long total = 0, mapped = 0;
+        double mapSeconds = 0;
+        std::string rec;
+        while (in.next(batch, opt.readsBatch))
+        {
+            auto m0 = std::chrono::steady_clock::now();
+            dy_reads * reads = nullptr;
+            check(dy_reads_upload(ctx, batch.codes.data(), batch.offs.data(), (uint32_t)batch.size(), &reads));
+            if (ibf)
+            {
+                // threshold from the batch-average read length (reference src/d_mapper.h:313-315)
+                uint16_t avg = (uint16_t)(batch.offs.back() * 2 / (batch.size() * 2));
+                dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
+                uint16_t thr = dy_ibf_threshold(opt.params.error_rate, info.kmer_size, avg);
+                if (thr == 0) std::cerr << "[WARNING!] 0 k-mer is required to filter a read!\nAll reads will pass filteration and be mapped everywhere.\n";
+                check(dy_ibf_query(ibf, reads, thr, nullptr));
+            }
+            dy_result * res = nullptr;
+            check(dy_map_reads(ctx, idx, reads, &opt.params, &res));
+            mapSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
+            const dy_read_result * rr = dy_result_reads(res);
+            const dy_match * ms = dy_result_matches(res);
+            const uint32_t * cg = dy_result_cigars(res);
+            // ---- SAM records (reference src/mapper_writer.h:296-345, 593-634)
+            for (size_t i = 0; i < batch.size(); ++i)
+            {
+                const dy_read_result & r = rr[i];
+                rec.clear();
+                const std::string & name = batch.names[i];
+                size_t cut = name.find_first_of(" \t/");
+                rec.append(name, 0, cut == std::string::npos ? name.size() : cut);
+                const u8 * codes = batch.codes.data() + batch.offs[i];
+                const char * quals = batch.quals.data() + batch.offs[i];
+                const size_t len = (size_t)(batch.offs[i + 1] - batch.offs[i]);
+                const bool rev = r.mapped && r.primary.is_rev;
+                if (!r.mapped) rec += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
+                else
+                {
+                    rec += rev ? "\t16\t" : "\t0\t";
+                    rec += dy_index_contig_name(idx, r.primary.contig); rec += '\t';
+                    appendUint(rec, (unsigned long long)r.primary.begin + 1); rec += '\t';
+                    appendUint(rec, r.mapq); rec += '\t';
+                    for (uint32_t k = 0; k < r.cigar_len; ++k) { uint32_t op = cg[r.cigar_begin + k]; appendUint(rec, op >> 4); rec += "MID"[op & 15]; }
+                    rec += "\t*\t0\t0\t";
+                }
+                if (!rev) { for (size_t k = 0; k < len; ++k) rec += "ACGTN"[codes[k]]; rec += '\t'; rec.append(quals, len); }
+                else
+                {
+                    for (size_t k = 0; k < len; ++k) { u8 c = codes[len - 1 - k]; rec += "ACGTN"[c < 4 ? 3 - c : 4]; }
+                    rec += '\t';
+                    for (size_t k = 0; k < len; ++k) rec += quals[len - 1 - k];
+                }
+                if (r.mapped)
+                {
+                    rec += "\tNM:i:"; appendUint(rec, r.primary.errors);
+                    rec += "\tX0:i:"; appendUint(rec, r.best_count);
+                    rec += "\tX1:i:"; appendUint(rec, r.sub_count);
+                }
+                rec += "\tRG:Z:"; rec += opt.readGroup;
+                if (r.mapped)
+                {   // XA: every entry of matchesSet except the primary (first entry with the primary's contig/strand/begin)
+                    bool skipped = false, any = false;
+                    const uint32_t nset = r.best_count + r.sub_count;
+                    for (uint32_t k = 0; k < nset; ++k)
+                    {
+                        const dy_match & m = ms[r.set_begin + k];
+                        if (!skipped && m.contig == r.primary.contig && m.is_rev == r.primary.is_rev && m.begin == r.primary.begin) { skipped = true; continue; }
+                        if (!any) { rec += "\tXA:Z:"; any = true; }
+                        rec += dy_index_contig_name(idx, m.contig); rec += ',';
+                        appendUint(rec, (unsigned long long)m.begin + 1); rec += ',';
+                        appendUint(rec, (unsigned long long)m.begin + m.length + 1); rec += ',';
+                        rec += m.is_rev ? '-' : '+'; rec += ',';
+                        appendUint(rec, m.errors); rec += ';';
+                    }
+                }
+                rec += '\n';
+                os << rec;
+                mapped += r.mapped;
+            }
+            total += batch.size();
+            dy_result_free(res);
+            dy_reads_free(reads);
+        }
+        os.flush();
+        if (opt.verbose)
+        {
+            dy_map_stats s; dy_map_get_stats(ctx, &s);
+            std::cerr << "Loading time:\t\t\t" << std::chrono::duration<double>(t1 - t0).count() << " sec\n"
+                      << "Mapping time:\t\t\t" << mapSeconds << " sec\n"
+                      << "Total reads:\t\t\t" << total << "\nMapped reads:\t\t\t" << mapped << "\n"
+                      << "Last batch: items " << s.items << ", raw matches " << s.raw_matches << ", hard items " << s.hard_items
+                      << ", ms ibf/items/search/extend/finalize " << s.ms_ibf << "/" << s.ms_items << "/" << s.ms_search << "/" << s.ms_extend << "/" << s.ms_finalize << "\n";
+        }
+        dy_index_free(idx);
+        if (ibf) dy_ibf_free(ibf);
+        dy_ctx_free(ctx);
+    }
+    catch (std::exception const & e)
+    {
+        std::cerr << "dream_yara_mapper: " << e.what() << std::endl;     // reference src/d_mapper.cpp:574-582
+        return 1;
+    }
+    return 0;
+}

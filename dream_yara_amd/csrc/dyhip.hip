@@ -1,0 +1,603 @@
+// libdyhip.so — C ABI (include/dyhip.h) over the gfx950 kernels. Host code is plumbing only: file parsing, HBM
+// allocation, kernel launches on one HIP stream, result mirroring. No compute falls back to the host.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/dyhip.h"
+#include "dy_types.h"
+#include "host_formats.hpp"
+#include "ibf_kernels.h"
+#include "map_kernels.h"
+#include "finalize_kernels.h"
+
+using namespace dy;
+
+namespace {
+
+thread_local std::string g_lastError;
+
+struct DyError
+{
+    int code; std::string msg;
+    DyError(int c, std::string m) : code(c), msg(std::move(m)) {}
+};
+
+#define HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    throw DyError(e_ == hipErrorOutOfMemory ? DY_ENOMEM : DY_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <typename F> int guarded(F && f)
+{
+    try { f(); return DY_OK; }
+    catch (DyError const & e) { g_lastError = e.msg; return e.code; }
+    catch (IoError const & e) { g_lastError = e.what(); return DY_EIO; }
+    catch (std::bad_alloc const &) { g_lastError = "host allocation failed"; return DY_ENOMEM; }
+    catch (std::exception const & e) { g_lastError = e.what(); return DY_EINVAL; }
+}
+
+// grow-only device buffer
+struct DevBuf
+{
+    void * p = nullptr; size_t cap = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf & operator=(const DevBuf &) = delete;
+    void reserve(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <typename T> T * as() const { return (T *)p; }
+};
+
+int deviceCount()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+} // namespace
+
+struct dy_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    dy_map_stats stats = {};
+    bool ibfTimingPending = false;
+    // workspaces (grow-only, reused across batches)
+    DevBuf waveCounts, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
+           cursor, gp, aux, marr, maux, dp, scanTmp;
+    size_t poolCap = 0;
+};
+
+struct dy_ibf
+{
+    dy_ctx * ctx = nullptr;
+    IbfGeom g = {};
+    DevBuf words;
+    size_t nWords = 0;
+};
+
+struct dy_reads
+{
+    dy_ctx * ctx = nullptr;
+    u32 n = 0; u64 totalBases = 0; u32 maxLen = 0; u32 minLen = 0;
+    DevBuf seqs, offs, masks;
+    u32 maskW = 0;       // words per read currently held in masks (0 = none)
+    u32 maskBins = 0;
+};
+
+struct dy_index
+{
+    dy_ctx * ctx = nullptr;
+    std::vector<BinDesc> bins;
+    std::vector<std::string> contigNames;
+    std::vector<u64> contigLengths;
+    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp;
+    IndexView view() const
+    {
+        IndexView v;
+        v.bins = dBins.as<BinDesc>(); v.rank = rank.as<uint4>(); v.ind = ind.as<uint2>(); v.valOffset = valOffset.as<u32>();
+        v.valContig = valContig.as<u16>(); v.contigs = contigs.as<u8>(); v.limits = limits.as<u64>(); v.drp = drp.as<u32>();
+        v.nBins = (u32)bins.size();
+        return v;
+    }
+};
+
+struct dy_result
+{
+    dy_ctx * ctx = nullptr;
+    u32 nReads = 0; u32 nPool = 0; u32 cigarStride = 0;
+    std::vector<u32> readLens;
+    DevBuf out, outSet, cigars;
+    bool fetched = false;
+    std::vector<dy_read_result> reads;
+    std::vector<dy_match> matches;
+    std::vector<u32> cigarOps;
+};
+
+template <typename T> static void upload(DevBuf & d, const std::vector<T> & h)
+{
+    d.reserve(h.size() * sizeof(T) + 64);
+    if (!h.empty()) HIP_CHECK(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+
+__global__ void k_fill_masks(u64 * masks, u32 nReads, u32 W, u32 nBins)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (u64)nReads * W) return;
+    const u32 w = (u32)(t % W);
+    const u32 left = nBins - w * 64;
+    masks[t] = left >= 64 ? ~0ull : ((1ull << left) - 1);
+}
+
+template <int NW>
+static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink)
+{
+    hipLaunchKernelGGL(k_extend<NW>, dim3((nItems + 255) / 256), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                       nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2);
+}
+
+// MAPQ — reference src/bits_matches.h:898-949, src/mapper_writer.h:221-225 (fp64, host libm like the reference)
+static double residualWeight(double errorRate) { double p = std::pow(10.0, std::min(2.0, 100.0 * errorRate - 7.0)); return p / (1.0 - p); }
+static double matchWeight(double errorRate, double optimalRate) { return (1.0 - errorRate) / std::pow(10.0, 300.0 * (errorRate - optimalRate)); }
+static unsigned mapqOf(unsigned errors, unsigned readLen, u64 best, u64 sub)
+{
+    double rate = (double)((float)errors / (float)readLen);
+    double w = best * matchWeight(rate, rate) + sub * matchWeight(rate + 0.01, rate) + residualWeight(rate);
+    double prob = matchWeight(rate, rate) / w;
+    return (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(prob, 0.9999999)));
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int dy_abi_version(void) { return DY_ABI_VERSION; }
+const char * dy_last_error(void) { return g_lastError.c_str(); }
+int dy_device_count(void) { return deviceCount(); }
+
+int dy_ctx_create(int device, dy_ctx ** out)
+{
+    return guarded([&] {
+        if (!out) throw DyError(DY_EINVAL, "dy_ctx_create: out is NULL");
+        int n = deviceCount();
+        if (n <= 0) throw DyError(DY_ENODEVICE, "no HIP device visible: libdyhip has no CPU fallback");
+        if (device < 0 || device >= n) throw DyError(DY_EINVAL, "device ordinal out of range");
+        HIP_CHECK(hipSetDevice(device));
+        std::unique_ptr<dy_ctx> c(new dy_ctx);
+        c->device = device;
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        for (auto & e : c->ev) HIP_CHECK(hipEventCreate(&e));
+        *out = c.release();
+    });
+}
+
+void dy_ctx_free(dy_ctx * ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    for (auto & e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int dy_ctx_sync(dy_ctx * ctx)
+{
+    return guarded([&] {
+        if (!ctx) throw DyError(DY_EINVAL, "ctx is NULL");
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+void * dy_ctx_stream(dy_ctx * ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- IBF ----------------------------------------------------------------------------------------------
+static void initGeom(IbfGeom & g, u32 bins, u32 hashes, u32 k, u64 bits)
+{
+    if (bins == 0 || hashes == 0 || hashes > 8) throw DyError(DY_EINVAL, "IBF: number of bins/hash functions out of range");
+    if (k == 0 || k > 32) throw DyError(DY_EUNSUPPORTED, "IBF: k-mer size must be in [1,32]");
+    if (bits < 256 + 64) throw DyError(DY_EINVAL, "IBF: filter too small");
+    if (bits % 64) throw DyError(DY_EUNSUPPORTED, "IBF: bit count must be a multiple of 64");
+    memset(&g, 0, sizeof(g));
+    g.nBits = bits; g.nBins = bins; g.nHashes = hashes; g.kmerSize = k;
+    g.W = (bins + 63) / 64;                                    // reference src/d_bloom_filter.h:247-249
+    if (g.W > 64) throw DyError(DY_EUNSUPPORTED, "IBF: more than 4096 bins are not supported");
+    g.nHashPos = (bits - 256) / (64ull * g.W);
+    if (g.nHashPos == 0) throw DyError(DY_EINVAL, "IBF: filter too small for the number of bins");
+    g.hashPosMask = (g.nHashPos & (g.nHashPos - 1)) == 0 ? g.nHashPos - 1 : 0;
+    if (g.nHashPos == 1) g.hashPosMask = 0;
+    for (u32 i = 0; i < hashes; ++i) g.preCalc[i] = (u64)i ^ ((u64)k * 0x90b45d39fb6da1faull);    // :251-253
+}
+
+int dy_ibf_create(dy_ctx * ctx, uint32_t n_bins, uint32_t n_hashes, uint32_t kmer_size, uint64_t n_bits, dy_ibf ** out)
+{
+    return guarded([&] {
+        if (!ctx || !out) throw DyError(DY_EINVAL, "dy_ibf_create: NULL argument");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::unique_ptr<dy_ibf> f(new dy_ibf);
+        f->ctx = ctx;
+        initGeom(f->g, n_bins, n_hashes, kmer_size, n_bits);
+        f->nWords = (size_t)(n_bits / 64);
+        f->words.reserve(f->nWords * 8 + 8);
+        HIP_CHECK(hipMemsetAsync(f->words.p, 0, f->nWords * 8 + 8, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *out = f.release();
+    });
+}
+
+int dy_ibf_load(dy_ctx * ctx, const char * path, dy_ibf ** out)
+{
+    return guarded([&] {
+        if (!ctx || !path || !out) throw DyError(DY_EINVAL, "dy_ibf_load: NULL argument");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        FilterFile ff(path);
+        u64 ms = ff.nBits - 256;                                // reference src/d_bloom_filter.h:255-265
+        u32 bins = (u32)ff.getInt(ms), hashes = (u32)ff.getInt(ms + 64), k = (u32)ff.getInt(ms + 128);
+        std::unique_ptr<dy_ibf> f(new dy_ibf);
+        f->ctx = ctx;
+        initGeom(f->g, bins, hashes, k, ff.nBits);
+        f->nWords = ff.nWords;
+        f->words.reserve(f->nWords * 8 + 8);
+        HIP_CHECK(hipMemcpy(f->words.p, ff.words, f->nWords * 8, hipMemcpyHostToDevice));
+        *out = f.release();
+    });
+}
+
+int dy_ibf_add(dy_ibf * f, const uint8_t * seq, uint64_t len, uint32_t bin)
+{
+    return guarded([&] {
+        if (!f || (!seq && len)) throw DyError(DY_EINVAL, "dy_ibf_add: NULL argument");
+        if (bin >= f->g.nBins) throw DyError(DY_EINVAL, "dy_ibf_add: bin out of range");
+        if (len < f->g.kmerSize) return;                        // reference src/d_bloom_filter.h:142-143
+        dy_ctx * ctx = f->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        DevBuf d; d.reserve(len);
+        HIP_CHECK(hipMemcpyAsync(d.p, seq, len, hipMemcpyHostToDevice, ctx->stream));
+        u64 nk = len - f->g.kmerSize + 1;
+        u32 blocks = (u32)((nk + 255) / 256);
+        hipLaunchKernelGGL(k_ibf_insert, dim3(blocks), dim3(256), 0, ctx->stream, f->words.as<u64>(), f->g, d.as<u8>(), len, bin);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int dy_ibf_save(dy_ibf * f, const char * path)
+{
+    return guarded([&] {
+        if (!f || !path) throw DyError(DY_EINVAL, "dy_ibf_save: NULL argument");
+        HIP_CHECK(hipSetDevice(f->ctx->device));
+        std::vector<u64> host(f->nWords);
+        HIP_CHECK(hipMemcpy(host.data(), f->words.p, f->nWords * 8, hipMemcpyDeviceToHost));
+        size_t ms = (size_t)((f->g.nBits - 256) / 64);          // _setMetadata, reference src/d_bloom_filter.h:267-277
+        host[ms] = f->g.nBins; host[ms + 1] = f->g.nHashes; host[ms + 2] = f->g.kmerSize;
+        FILE * fp = fopen(path, "wb");
+        if (!fp) throw IoError(std::string("cannot write ") + path);
+        bool ok = fwrite(&f->g.nBits, 8, 1, fp) == 1 && fwrite(host.data(), 8, host.size(), fp) == host.size();
+        fclose(fp);
+        if (!ok) throw IoError(std::string("short write to ") + path);
+    });
+}
+
+int dy_ibf_get_info(const dy_ibf * f, dy_ibf_info * info)
+{
+    if (!f || !info) { g_lastError = "NULL argument"; return DY_EINVAL; }
+    info->n_bits = f->g.nBits; info->n_bins = f->g.nBins; info->n_hashes = f->g.nHashes; info->kmer_size = f->g.kmerSize;
+    info->words_per_pos = f->g.W; info->n_hash_pos = f->g.nHashPos;
+    return DY_OK;
+}
+
+void dy_ibf_free(dy_ibf * f) { if (f) { (void)hipSetDevice(f->ctx->device); delete f; } }
+
+uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len)
+{
+    uint16_t maxError = (uint16_t)(error_rate * read_len);
+    if (kmer_size * (1u + maxError) > read_len) return 0;
+    return (uint16_t)(read_len - kmer_size * (1u + maxError) + 1);
+}
+
+// ---- reads --------------------------------------------------------------------------------------------
+int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, uint32_t n_reads, dy_reads ** out)
+{
+    return guarded([&] {
+        if (!ctx || !offs || !out || (!seqs && n_reads && offs[n_reads])) throw DyError(DY_EINVAL, "dy_reads_upload: NULL argument");
+        if (n_reads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::unique_ptr<dy_reads> r(new dy_reads);
+        r->ctx = ctx; r->n = n_reads; r->totalBases = offs[n_reads];
+        u32 mx = 0, mn = 0xFFFFFFFFu;
+        for (u32 i = 0; i < n_reads; ++i)
+        {
+            if (offs[i + 1] < offs[i]) throw DyError(DY_EINVAL, "read offsets must be non-decreasing");
+            u64 l = offs[i + 1] - offs[i];
+            if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");      // reference src/mapper.h:453-454
+            mx = std::max<u32>(mx, (u32)l); mn = std::min<u32>(mn, (u32)l);
+        }
+        r->maxLen = mx; r->minLen = n_reads ? mn : 0;
+        r->seqs.reserve(r->totalBases + 64);
+        r->offs.reserve((size_t)(n_reads + 1) * 8);
+        if (r->totalBases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs, r->totalBases, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(r->offs.p, offs, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *out = r.release();
+    });
+}
+
+uint32_t dy_reads_count(const dy_reads * r) { return r ? r->n : 0; }
+void dy_reads_free(dy_reads * r) { if (r) { (void)hipSetDevice(r->ctx->device); delete r; } }
+
+int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bin_masks_host)
+{
+    return guarded([&] {
+        if (!f || !reads) throw DyError(DY_EINVAL, "dy_ibf_query: NULL argument");
+        if (f->ctx != reads->ctx) throw DyError(DY_EINVAL, "filter and reads belong to different contexts");
+        dy_ctx * ctx = f->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 W = f->g.W;
+        reads->masks.reserve((size_t)reads->n * W * 8 + 8);
+        reads->maskW = W; reads->maskBins = f->g.nBins;
+        if (reads->n)
+        {
+            const u32 wavesPerBlock = 4;
+            size_t lds = (size_t)wavesPerBlock * 64 * W * sizeof(u16);
+            HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+            hipLaunchKernelGGL(k_ibf_query, dim3((reads->n + wavesPerBlock - 1) / wavesPerBlock), dim3(64 * wavesPerBlock), lds, ctx->stream,
+                               f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(), reads->n, (u32)threshold,
+                               reads->masks.as<u64>());
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
+        }
+        if (bin_masks_host)
+        {
+            if (reads->n) HIP_CHECK(hipMemcpyAsync(bin_masks_host, reads->masks.p, (size_t)reads->n * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (reads->n) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; }
+        }
+        else if (reads->n) ctx->ibfTimingPending = true;
+    });
+}
+
+// ---- index --------------------------------------------------------------------------------------------
+int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** out)
+{
+    return guarded([&] {
+        if (!ctx || !dir || !out) throw DyError(DY_EINVAL, "dy_index_load: NULL argument");
+        if (n_bins == 0 || n_bins > 4096) throw DyError(DY_EINVAL, "number of bins out of range");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::string d(dir);
+        while (d.size() > 1 && d.back() == '/') d.pop_back();
+        HostIndex H;
+        for (u32 b = 0; b < n_bins; ++b) appendBin(H, d + "/" + std::to_string(b));
+        std::unique_ptr<dy_index> idx(new dy_index);
+        idx->ctx = ctx;
+        idx->bins = H.bins; idx->contigNames = H.contigNames; idx->contigLengths = H.contigLengths;
+        upload(idx->dBins, H.bins); upload(idx->rank, H.rank); upload(idx->ind, H.ind); upload(idx->valOffset, H.valOffset);
+        upload(idx->valContig, H.valContig); upload(idx->contigs, H.contigs); upload(idx->limits, H.limits); upload(idx->drp, H.drp);
+        *out = idx.release();
+    });
+}
+
+uint32_t dy_index_bins(const dy_index * idx) { return idx ? (uint32_t)idx->bins.size() : 0; }
+uint32_t dy_index_contigs(const dy_index * idx) { return idx ? (uint32_t)idx->contigNames.size() : 0; }
+const char * dy_index_contig_name(const dy_index * idx, uint32_t c) { return (idx && c < idx->contigNames.size()) ? idx->contigNames[c].c_str() : nullptr; }
+uint64_t dy_index_contig_length(const dy_index * idx, uint32_t c) { return (idx && c < idx->contigLengths.size()) ? idx->contigLengths[c] : 0; }
+void dy_index_free(dy_index * idx) { if (idx) { (void)hipSetDevice(idx->ctx->device); delete idx; } }
+
+// ---- mapping ------------------------------------------------------------------------------------------
+void dy_params_default(dy_params * p)
+{
+    if (!p) return;
+    p->error_rate = 0.05f; p->strata_rate = 0.0f; p->sensitivity = 1; p->hits_threshold = 300; p->use_filter = 1; p->reserved = 0;
+}
+
+int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, dy_result ** out)
+{
+    return guarded([&] {
+        if (!ctx || !idx || !reads || !p || !out) throw DyError(DY_EINVAL, "dy_map_reads: NULL argument");
+        if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
+        if (p->sensitivity > 1) throw DyError(DY_EUNSUPPORTED, "sensitivity 'full' (edit-distance seeds) is not implemented");
+        if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
+        const u32 maxErr = readErrorsOf(reads->maxLen, p->error_rate);
+        const u32 S0 = seedCountOf(maxErr, 0);
+        if (S0 > MAX_SEEDS) throw DyError(DY_EUNSUPPORTED, "more than 32 seeds per read (read length x error rate too large)");
+        if (nBins > 65535) throw DyError(DY_EUNSUPPORTED, "too many bins");
+
+        if (!p->use_filter)
+        {
+            reads->masks.reserve((size_t)nReads * W * 8 + 8);
+            reads->maskW = W; reads->maskBins = nBins;
+            if (nReads) hipLaunchKernelGGL(k_fill_masks, dim3((u32)(((u64)nReads * W + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins);
+        }
+        else if (reads->maskW != W || reads->maskBins != nBins)
+            throw DyError(DY_EINVAL, "dy_ibf_query must run on these reads first (with a filter of the index's bin count)");
+
+        std::unique_ptr<dy_result> res(new dy_result);
+        res->ctx = ctx; res->nReads = nReads; res->cigarStride = 2 * maxErr + 1;
+        res->out.reserve((size_t)nReads * sizeof(ReadOut) + 64);
+        res->cigars.reserve((size_t)nReads * res->cigarStride * 4 + 64);
+        ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
+        if (nReads == 0) { *out = res.release(); return; }
+
+        // ---- work list (bin-major)
+        HIP_CHECK(hipEventRecord(ctx->ev[2], st));
+        const u32 nWaves = (nReads + 63) / 64;
+        ctx->waveCounts.reserve((size_t)nBins * nWaves * 4);
+        ctx->binTotals.reserve((size_t)nBins * 4); ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
+        hipLaunchKernelGGL(k_items_count, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins, ctx->waveCounts.as<u32>());
+        hipLaunchKernelGGL(k_items_scan_bins, dim3((nBins + 63) / 64), dim3(64), 0, st, ctx->waveCounts.as<u32>(), nWaves, nBins, ctx->binTotals.as<u32>());
+        hipLaunchKernelGGL(k_items_bin_starts, dim3(1), dim3(64), 0, st, ctx->binTotals.as<u32>(), nBins, ctx->binStart.as<u32>(), ctx->binOrderRank.as<u32>());
+        u32 nItems = 0;
+        HIP_CHECK(hipMemcpyAsync(&nItems, ctx->binStart.as<u32>() + nBins, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (ctx->ibfTimingPending) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; ctx->ibfTimingPending = false; }
+        ctx->stats.items = nItems;
+        ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
+        if (nItems)
+            hipLaunchKernelGGL(k_items_scatter, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins,
+                               ctx->waveCounts.as<u32>(), ctx->binStart.as<u32>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>());
+        HIP_CHECK(hipEventRecord(ctx->ev[3], st));
+
+        // ---- K2: exact search of the round-0 seeds
+        const IndexView ix = idx->view();
+        ReadsView rv; rv.seqs = reads->seqs.as<u8>(); rv.offs = reads->offs.as<u64>(); rv.nReads = nReads;
+        MapParams mp; mp.errorRate = p->error_rate; mp.strataRate = p->strata_rate; mp.sensitivity = p->sensitivity; mp.hitsThreshold = p->hits_threshold;
+        ctx->hits0.reserve((size_t)nItems * 2 * S0 * sizeof(uint2) + 64);
+        if (nItems)
+        {
+            u64 threads = (u64)nItems * 2 * S0;
+            hipLaunchKernelGGL(k_seed_search, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                               nItems, S0, mp.errorRate, ctx->hits0.as<uint2>());
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev[4], st));
+
+        // ---- K3: classify, rank, locate, extend -> raw match pool (grown and re-run on overflow)
+        ctx->counters.reserve(64);
+        ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
+        if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
+        u32 hostCounters[4] = {0, 0, 0, 0};     // [0] pool count, [1] overflow flag, [2] hard items
+        const int nw = (int)((reads->maxLen + 63) / 64);
+        for (;;)
+        {
+            ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
+            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 16, st));
+            HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
+            MatchSink sink; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
+            sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
+            if (nItems)
+            {
+                if (nw <= 2) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink);
+                else if (nw <= 4) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink);
+                else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink);
+                else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink);
+                HIP_CHECK(hipGetLastError());
+            }
+            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, 16, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (!hostCounters[1]) break;
+            if (hostCounters[0] >= 0xFFFFFFF0u) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+            ctx->poolCap = (size_t)hostCounters[0] + (size_t)hostCounters[0] / 4 + 1024;
+            ctx->stats.pool_retries++;
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev[5], st));
+        const u32 nPool = hostCounters[0];
+        ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2];
+        res->nPool = nPool;
+
+        // ---- group by read, then per-read aggregation
+        ctx->readStart.reserve((size_t)(nReads + 1) * 4);
+        size_t tmpBytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->readMatchCount.as<u32>(), ctx->readStart.as<u32>(), (int)(nReads + 1), st));
+        ctx->scanTmp.reserve(tmpBytes + 64);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->readMatchCount.as<u32>(), ctx->readStart.as<u32>(), (int)(nReads + 1), st));
+        ctx->cursor.reserve((size_t)nReads * 4 + 64);
+        HIP_CHECK(hipMemsetAsync(ctx->cursor.p, 0, (size_t)nReads * 4, st));
+        ctx->gp.reserve((size_t)nPool * sizeof(RawMatch) + 64);
+        if (nPool)
+            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, ctx->pool.as<RawMatch>(), nPool, ctx->readStart.as<u32>(),
+                               ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>());
+        ctx->aux.reserve((size_t)nPool * 16 + 64);
+        ctx->marr.reserve((size_t)nPool * 3 * sizeof(RawMatch) + 64);
+        ctx->maux.reserve((size_t)nPool * 6 * 4 + 64);
+        res->outSet.reserve((size_t)nPool * 3 * sizeof(OutMatch) + 64);
+        const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
+        const size_t dpStride = (dpScratchBytes(reads->maxLen, maxErr) + 15) & ~(size_t)15;
+        ctx->dp.reserve(dpStride * finWaves + 64);
+        FinalizeArgs fa;
+        fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.nReads = nReads;
+        fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate;
+        fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
+        fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
+        hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(ctx->ev[6], st));
+
+        // read lengths for the host-side MAPQ
+        res->readLens.resize(nReads);
+        std::vector<u64> offs(nReads + 1);
+        HIP_CHECK(hipMemcpyAsync(offs.data(), reads->offs.p, (size_t)(nReads + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        for (u32 i = 0; i < nReads; ++i) res->readLens[i] = (u32)(offs[i + 1] - offs[i]);
+        float ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_extend = ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->stats.ms_finalize = ms;
+        *out = res.release();
+    });
+}
+
+int dy_result_fetch(dy_result * r)
+{
+    return guarded([&] {
+        if (!r) throw DyError(DY_EINVAL, "result is NULL");
+        if (r->fetched) return;
+        dy_ctx * ctx = r->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::vector<ReadOut> ro(r->nReads);
+        std::vector<OutMatch> os((size_t)r->nPool * 3);
+        std::vector<u32> cg((size_t)r->nReads * r->cigarStride);
+        if (r->nReads) HIP_CHECK(hipMemcpyAsync(ro.data(), r->out.p, ro.size() * sizeof(ReadOut), hipMemcpyDeviceToHost, ctx->stream));
+        if (!os.empty()) HIP_CHECK(hipMemcpyAsync(os.data(), r->outSet.p, os.size() * sizeof(OutMatch), hipMemcpyDeviceToHost, ctx->stream));
+        if (!cg.empty()) HIP_CHECK(hipMemcpyAsync(cg.data(), r->cigars.p, cg.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        r->reads.resize(r->nReads);
+        r->matches.clear(); r->cigarOps.clear();
+        for (u32 i = 0; i < r->nReads; ++i)
+        {
+            const ReadOut & o = ro[i];
+            dy_read_result & d = r->reads[i];
+            d.primary.contig = o.contig; d.primary.begin = o.begin; d.primary.length = o.length; d.primary.errors = o.errors; d.primary.is_rev = o.isRev;
+            d.mapped = o.mapped; d.best_count = o.bestCount; d.sub_count = o.subCount;
+            d.mapq = o.mapped ? mapqOf(o.errors, r->readLens[i], o.bestCount, o.subCount) : 0;
+            d.set_begin = (u32)r->matches.size();
+            u32 nset = o.bestCount + o.subCount;
+            for (u32 k = 0; k < nset; ++k)
+            {
+                const OutMatch & m = os[(size_t)o.setBegin + k];
+                dy_match dm; dm.contig = m.contig; dm.begin = m.begin; dm.length = m.length; dm.errors = m.errors; dm.is_rev = m.isRev;
+                r->matches.push_back(dm);
+            }
+            d.cigar_begin = (u32)r->cigarOps.size(); d.cigar_len = o.mapped ? o.cigarLen : 0;
+            for (u32 k = 0; k < d.cigar_len; ++k) r->cigarOps.push_back(cg[(size_t)o.cigarBegin + k]);
+        }
+        r->fetched = true;
+    });
+}
+
+int dy_map_reads(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, dy_result ** out)
+{
+    int rc = dy_map_reads_async(ctx, idx, reads, p, out);
+    if (rc != DY_OK) return rc;
+    rc = dy_result_fetch(*out);
+    if (rc != DY_OK) { dy_result_free(*out); *out = nullptr; }
+    return rc;
+}
+
+const dy_read_result * dy_result_reads(const dy_result * r) { return (r && r->fetched) ? r->reads.data() : nullptr; }
+const dy_match * dy_result_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.data() : nullptr; }
+uint64_t dy_result_n_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.size() : 0; }
+const uint32_t * dy_result_cigars(const dy_result * r) { return (r && r->fetched) ? r->cigarOps.data() : nullptr; }
+void dy_result_free(dy_result * r) { if (r) { (void)hipSetDevice(r->ctx->device); delete r; } }
+
+int dy_map_get_stats(const dy_ctx * ctx, dy_map_stats * s)
+{
+    if (!ctx || !s) { g_lastError = "NULL argument"; return DY_EINVAL; }
+    *s = ctx->stats;
+    return DY_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,126 @@
+// Device-side FM-index primitives over the reference's own on-disk layout:
+// rank over 32-byte blocks of lf.drv, LF-mapping with the sentinel correction, backward search step
+// (reference src/index_fm.h:132-155) and the sparse-SA walk of SeqAn's CompressedSA (SAMPLING = 10,
+// reference src/misc_types.h:174).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dy_types.h"
+
+namespace dy {
+
+// Pointers into the device arena shared by all bins.
+struct IndexView
+{
+    const BinDesc * bins;
+    const uint4 *   rank;       // 2 x uint4 per block: {sym0.lo, sym0.hi, sym1.lo, sym1.hi}, {cntA, cntC, cntG, cntT}
+    const uint2 *   ind;        // {bits, onesBefore}
+    const u32 *     valOffset;
+    const u16 *     valContig;
+    const u8 *      contigs;
+    const u64 *     limits;
+    const u32 *     drp;
+    u32             nBins;
+};
+
+struct BinView
+{
+    const uint4 * rank;
+    const uint2 * ind;
+    const u32 *   valOffset;
+    const u16 *   valContig;
+    const u8 *    contigs;      // base of this bin's concatenated contigs
+    const u64 *   limits;       // nContigs + 1
+    const u32 *   drp;
+    u32 n, nContigs, drs;
+    u32 pst[4];
+};
+
+__device__ __forceinline__ BinView makeBinView(const IndexView & ix, u32 bin)
+{
+    const BinDesc & d = ix.bins[bin];
+    BinView b;
+    b.rank = ix.rank + d.rankOff * 2;
+    b.ind = ix.ind + d.indOff;
+    b.valOffset = ix.valOffset + d.valOff;
+    b.valContig = ix.valContig + d.valOff;
+    b.contigs = ix.contigs + d.contigOff;
+    b.limits = ix.limits + d.limOff;
+    b.drp = ix.drp + d.drpOff;
+    b.n = d.n; b.nContigs = d.nContigs; b.drs = d.drs;
+    b.pst[0] = d.pst[0]; b.pst[1] = d.pst[1]; b.pst[2] = d.pst[2]; b.pst[3] = d.pst[3];
+    return b;
+}
+
+__device__ __forceinline__ u32 sel4(uint4 v, u32 c) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; }
+
+// number of symbols equal to c among the first `off` (0..63) symbols of a block (symbol t sits at bits (31 - t%32)*2 of word t/32)
+__device__ __forceinline__ u32 countInBlock(uint4 sym, u32 c, u32 off)
+{
+    const u64 rep = 0x5555555555555555ull * c;
+    u64 w0 = ((u64)sym.y << 32) | sym.x, w1 = ((u64)sym.w << 32) | sym.z;
+    u64 x0 = ~(w0 ^ rep), x1 = ~(w1 ^ rep);
+    u64 m0 = x0 & (x0 >> 1) & 0x5555555555555555ull, m1 = x1 & (x1 >> 1) & 0x5555555555555555ull;
+    u32 k0 = off < 32 ? off : 32, k1 = off < 32 ? 0 : off - 32;
+    if (k0 < 32) m0 = k0 ? (m0 & (~0ull << (64 - 2 * k0))) : 0;
+    m1 = k1 ? (m1 & (~0ull << (64 - 2 * k1))) : 0;
+    return __popcll(m0) + __popcll(m1);
+}
+
+// #sentinel rows < pos
+__device__ __forceinline__ u32 sentinelsBefore(const BinView & b, u32 pos)
+{
+    if (b.nContigs == 1) return b.drp[0] < pos;
+    u32 lo = 0, hi = b.nContigs;
+    while (lo < hi) { u32 mid = (lo + hi) >> 1; if (b.drp[mid] < pos) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// LF(pos, c) = C[c] + rank_c(bwt[0..pos))
+__device__ __forceinline__ u32 lfMap(const BinView & b, u32 pos, u32 c)
+{
+    const uint4 * blk = b.rank + (size_t)(pos >> 6) * 2;
+    uint4 sym = blk[0], cnt = blk[1];
+    u32 r = sel4(cnt, c) + countInBlock(sym, c, pos & 63);
+    if (c == b.drs) r -= sentinelsBefore(b, pos);
+    return b.pst[c] + r;
+}
+
+__device__ __forceinline__ u32 bwtSymbol(const BinView & b, u32 row)
+{
+    uint4 sym = b.rank[(size_t)(row >> 6) * 2];
+    u32 t = row & 63;
+    u32 word = t < 32 ? (((t & 31) < 16) ? sym.y : sym.x) : (((t & 31) < 16) ? sym.w : sym.z);
+    // symbol t%32 sits at bits (31 - t%32)*2 of the 64-bit word: t%32 < 16 -> high dword
+    u32 sh = ((31 - (t & 31)) * 2) & 31;
+    return (word >> sh) & 3;
+}
+
+// one backward-search step on both range ends; false when the range becomes empty
+__device__ __forceinline__ bool fmStep(const BinView & b, u32 & lo, u32 & hi, u32 c)
+{
+    lo = lfMap(b, lo, c);
+    hi = lfMap(b, hi, c);
+    return lo < hi;
+}
+
+// SA[row] -> (contig, offset in the REVERSED contig)
+__device__ __forceinline__ void fmLocate(const BinView & b, u32 row, u32 & contig, u32 & offset)
+{
+    u32 steps = 0;
+    for (;;)
+    {
+        uint2 e = b.ind[row >> 5];
+        u32 bit = 31 - (row & 31);
+        if ((e.x >> bit) & 1)
+        {
+            u32 idx = e.y + (bit == 31 ? 0u : (u32)__popc(e.x >> (bit + 1)));
+            contig = b.valContig[idx];
+            offset = b.valOffset[idx] + steps;
+            return;
+        }
+        row = lfMap(b, row, bwtSymbol(b, row));
+        ++steps;
+    }
+}
+
+} // namespace dy

@@ -1,0 +1,250 @@
+// Host-side readers for the reference's on-disk inputs (no SeqAn / sdsl): the 12 per-bin index files,
+// the .filter file and FASTA/FASTQ reads.  Everything is parsed straight into the flat arenas that are
+// uploaded to HBM (see DESIGN.md "Data layout").  File formats: SURVEY.md Appendix A; producer side in the
+// reference: src/index_fm.h:68-82, src/store_seqs.h:143-158, src/misc_options.h:293-307, src/d_bloom_filter.h:150-154.
+#pragma once
+#include "dy_types.h"
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <cstdio>
+#include <cstring>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+namespace dy {
+
+struct IoError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// Read-only memory map of a whole file.
+class MappedFile
+{
+public:
+    explicit MappedFile(const std::string & path)
+    {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) throw IoError("cannot open " + path);
+        struct stat st;
+        if (fstat(fd_, &st) != 0) { ::close(fd_); throw IoError("cannot stat " + path); }
+        size_ = (size_t)st.st_size;
+        if (size_)
+        {
+            ptr_ = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+            if (ptr_ == MAP_FAILED) { ::close(fd_); throw IoError("cannot map " + path); }
+        }
+    }
+    ~MappedFile() { if (ptr_ && ptr_ != MAP_FAILED) munmap(ptr_, size_); if (fd_ >= 0) ::close(fd_); }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile & operator=(const MappedFile &) = delete;
+    const u8 * data() const { return (const u8 *)ptr_; }
+    size_t size() const { return size_; }
+private:
+    int fd_ = -1; void * ptr_ = nullptr; size_t size_ = 0;
+};
+
+template <typename T> inline T loadLE(const u8 * p) { T v; memcpy(&v, p, sizeof(T)); return v; }
+
+// Host image of the whole index (all bins), laid out exactly like the device arena.
+struct HostIndex
+{
+    std::vector<BinDesc> bins;
+    std::vector<u8>  rank;          // 32 B blocks
+    std::vector<u8>  ind;           // 8 B entries
+    std::vector<u32> valOffset;     // SA sample offsets
+    std::vector<u16> valContig;     // SA sample contig ids
+    std::vector<u8>  contigs;       // 1 B/base Dna5 codes, all bins back to back
+    std::vector<u64> limits;        // per bin: nContigs+1 prefix sums
+    std::vector<u32> drp;           // sentinel rows
+    std::vector<std::string> contigNames;   // global order
+    std::vector<u64> contigLengths;
+};
+
+inline void appendBin(HostIndex & H, const std::string & prefix)
+{
+    BinDesc d; memset(&d, 0, sizeof(d));
+    MappedFile size(prefix + ".txt.size");
+    if (size.size() != 24) throw IoError("Error while opening reference file.");
+    u64 nContigs = loadLE<u64>(size.data() + 8), sum = loadLE<u64>(size.data() + 16);
+    if (nContigs == 0 || nContigs > 255) throw IoError("bins with 0 or more than 255 contigs are not supported (" + prefix + ")");
+    d.nContigs = (u32)nContigs;
+    d.contigIdBase = (u32)H.contigNames.size();
+
+    // contigs: txt.limits (u64 prefix sums) + txt.concat (word 0 = length, then 21 bases / u64, 3 bit each, MSB first)
+    {
+        MappedFile lim(prefix + ".txt.limits"), cc(prefix + ".txt.concat");
+        if (lim.size() != (nContigs + 1) * 8 || cc.size() < 8) throw IoError("Error while opening reference file.");
+        d.limOff = (u32)H.limits.size();
+        for (u64 i = 0; i <= nContigs; ++i) H.limits.push_back(loadLE<u64>(lim.data() + i * 8));
+        u64 len = loadLE<u64>(cc.data());
+        if (len != sum || (cc.size() - 8) / 8 * 21 < len) throw IoError("txt.concat does not match txt.size in " + prefix);
+        d.contigOff = H.contigs.size();
+        H.contigs.resize(d.contigOff + len);
+        u8 * out = H.contigs.data() + d.contigOff;
+        const u8 * w = cc.data() + 8;
+        for (u64 base = 0; base < len; base += 21, w += 8)
+        {
+            u64 word = loadLE<u64>(w);
+            u64 lim21 = len - base < 21 ? len - base : 21;
+            for (u64 k = 0; k < lim21; ++k) out[base + k] = (u8)((word >> (60 - 3 * k)) & 7);
+        }
+        for (u64 i = 0; i < nContigs; ++i) H.contigLengths.push_back(H.limits[d.limOff + i + 1] - H.limits[d.limOff + i]);
+    }
+    // names: rid.limits (u32) + rid.concat
+    {
+        MappedFile rl(prefix + ".rid.limits"), rc(prefix + ".rid.concat");
+        if (rl.size() != (nContigs + 1) * 4) throw IoError("Error while opening reference file.");
+        for (u64 i = 0; i < nContigs; ++i)
+        {
+            u32 a = loadLE<u32>(rl.data() + i * 4), b = loadLE<u32>(rl.data() + i * 4 + 4);
+            if (b < a || b > rc.size()) throw IoError("corrupt rid.limits in " + prefix);
+            H.contigNames.emplace_back((const char *)rc.data() + a, (const char *)rc.data() + b);
+        }
+    }
+    // FM index
+    {
+        MappedFile len(prefix + ".sa.len"), pst(prefix + ".lf.pst"), drv(prefix + ".lf.drv"), drs(prefix + ".lf.drs"),
+                   drp(prefix + ".lf.drp"), ind(prefix + ".sa.ind"), val(prefix + ".sa.val");
+        if (len.size() != 4 || pst.size() != 20 || drs.size() != 1 || drv.size() % 32 || ind.size() % 8)
+            throw IoError("Error while opening reference index file.");
+        d.n = loadLE<u32>(len.data());
+        if (d.n != sum + nContigs) throw IoError("sa.len does not match txt.size in " + prefix);
+        for (int c = 0; c < 4; ++c) d.pst[c] = loadLE<u32>(pst.data() + 4 * c);
+        d.drs = drs.data()[0];
+        if (drp.size() != nContigs * 4) throw IoError("unexpected lf.drp size in " + prefix);
+        d.drpOff = (u32)H.drp.size();
+        for (u64 i = 0; i < nContigs; ++i) H.drp.push_back(loadLE<u32>(drp.data() + 4 * i));
+        // rank blocks; rank(.., n) with n % 64 == 0 touches one block past the file: synthesise it
+        d.rankOff = H.rank.size() / 32;
+        size_t nblk = drv.size() / 32;
+        if (nblk * 64 < d.n) throw IoError("lf.drv too short in " + prefix);
+        H.rank.insert(H.rank.end(), drv.data(), drv.data() + drv.size());
+        if (nblk * 64 <= d.n)
+        {
+            const u8 * last = drv.data() + (nblk - 1) * 32;
+            u64 s0 = loadLE<u64>(last), s1 = loadLE<u64>(last + 8);
+            u32 cnt[4];
+            for (int c = 0; c < 4; ++c) cnt[c] = loadLE<u32>(last + 16 + 4 * c);
+            for (int t = 0; t < 64; ++t) cnt[((t < 32 ? s0 : s1) >> ((31 - (t & 31)) * 2)) & 3]++;
+            u8 extra[32]; memset(extra, 0, 32); memcpy(extra + 16, cnt, 16);
+            H.rank.insert(H.rank.end(), extra, extra + 32);
+        }
+        d.indOff = H.ind.size() / 8;
+        if (ind.size() / 8 * 32 < d.n) throw IoError("sa.ind too short in " + prefix);
+        H.ind.insert(H.ind.end(), ind.data(), ind.data() + ind.size());
+        // sa.val: packed (u8 contig, u32 offset) for bins with <= 255 contigs (reference src/misc_types.h:184-188)
+        if (val.size() % 5) throw IoError("unexpected sa.val record size in " + prefix);
+        d.valOff = H.valOffset.size();
+        size_t nval = val.size() / 5;
+        for (size_t i = 0; i < nval; ++i)
+        {
+            H.valContig.push_back(val.data()[i * 5]);
+            H.valOffset.push_back(loadLE<u32>(val.data() + i * 5 + 1));
+        }
+    }
+    H.bins.push_back(d);
+}
+
+// .filter file = sdsl::bit_vector: u64 bit count, then ceil(bits/64) words.
+struct FilterFile
+{
+    MappedFile map;
+    u64 nBits = 0;
+    const u8 * words = nullptr;
+    size_t nWords = 0;
+    explicit FilterFile(const std::string & path) : map(path)
+    {
+        if (map.size() < 8 + 32) throw IoError("File \"" + path + "\" could not be read.");
+        nBits = loadLE<u64>(map.data());
+        nWords = (size_t)((nBits + 63) / 64);
+        if (nBits < 256 || map.size() < 8 + nWords * 8) throw IoError("File \"" + path + "\" could not be read.");
+        words = map.data() + 8;
+    }
+    u64 getInt(u64 bit) const   // sdsl get_int(bit, 64)
+    {
+        u64 w = bit >> 6; unsigned o = bit & 63;
+        u64 lo = loadLE<u64>(words + w * 8);
+        if (!o) return lo;
+        u64 hi = w + 1 < nWords ? loadLE<u64>(words + (w + 1) * 8) : 0;
+        return (lo >> o) | (hi << (64 - o));
+    }
+};
+
+inline u8 dna5Code(char c)
+{
+    switch (c)
+    {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+// Streaming FASTA/FASTQ reader producing SoA batches (codes + offsets) ready for dy_reads_upload.
+struct ReadsBatch
+{
+    std::vector<std::string> names;
+    std::vector<u8>  codes;     // forward reads back to back
+    std::vector<u64> offs;      // n+1
+    std::vector<char> quals;    // same layout as codes; 'I' for FASTA, '!' under N
+    size_t size() const { return names.size(); }
+    void clear() { names.clear(); codes.clear(); offs.assign(1, 0); quals.clear(); }
+};
+
+class ReadsFile
+{
+public:
+    explicit ReadsFile(const std::string & path) : map_(path), p_(map_.data()), end_(map_.data() + map_.size()) {}
+    // appends up to maxReads records; returns the number appended
+    size_t next(ReadsBatch & b, size_t maxReads)
+    {
+        b.clear();
+        size_t n = 0;
+        while (n < maxReads)
+        {
+            skipBlank();
+            if (p_ >= end_) break;
+            char marker = (char)*p_;
+            if (marker != '>' && marker != '@') throw IoError("unrecognised reads file format");
+            std::string header = line();
+            b.names.push_back(header.substr(1));
+            size_t start = b.codes.size();
+            if (marker == '>')
+            {
+                while (p_ < end_ && *p_ != '>') { std::string s = line(); for (char c : s) b.codes.push_back(dna5Code(c)); }
+                b.quals.resize(b.codes.size(), 'I');
+            }
+            else
+            {
+                std::string s = line(); for (char c : s) b.codes.push_back(dna5Code(c));
+                line();                                   // '+'
+                std::string q = line();
+                b.quals.resize(b.codes.size(), 'I');
+                for (size_t i = 0; i < q.size() && start + i < b.codes.size(); ++i)
+                    b.quals[start + i] = (char)(q[i] > 33 + 62 ? 33 + 62 : q[i]);   // Dna5Q keeps 6 quality bits
+            }
+            for (size_t i = start; i < b.codes.size(); ++i) if (b.codes[i] == 4) b.quals[i] = '!';   // N carries no quality
+            b.offs.push_back(b.codes.size());
+            ++n;
+        }
+        return n;
+    }
+private:
+    void skipBlank() { while (p_ < end_ && (*p_ == '\n' || *p_ == '\r')) ++p_; }
+    std::string line()
+    {
+        const u8 * s = p_;
+        while (p_ < end_ && *p_ != '\n') ++p_;
+        const u8 * e = p_;
+        if (p_ < end_) ++p_;
+        while (e > s && (e[-1] == '\r' || e[-1] == ' ')) --e;
+        return std::string((const char *)s, (const char *)e);
+    }
+    MappedFile map_;
+    const u8 * p_; const u8 * end_;
+};
+
+} // namespace dy

@@ -1,0 +1,503 @@
+// K2 (seed search) and K3 (classify, rank, locate, extend) for gfx950, plus the read->bin work-list kernels.
+// One work item = one (read, bin) pair selected by the IBF = one read of one child mapper in the reference.
+//   work list        replaces loadFilteredReads                         reference src/d_mapper.h:394-443
+//   K2 k_seed_search replaces collectSeeds<0> + findSeeds<0>(bucket 0)  reference src/mapper.h:581-649, src/mapper_collector.h:143-160,
+//                                                                       src/index_fm.h:132-155, src/mapper_filter.h:62-68
+//   K3 k_extend      replaces classifyReads, rankSeeds, extendHits<0..2> and the re-seeding rounds of _mapReadsImpl
+//                                                                       reference src/d_mapper.h:257-294, src/mapper_classifier.h:111-155,
+//                                                                       src/mapper_ranker.h:122-177, src/mapper_extender.h:147-308,
+//                                                                       src/find_extender.h:87-403
+// Work items are laid out bin-major, so neighbouring workgroups walk the same bin's rank blocks (L2 reuse).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dy_types.h"
+#include "fm_device.h"
+
+namespace dy {
+
+struct ReadsView
+{
+    const u8 *  seqs;     // forward reads, Dna5 codes
+    const u64 * offs;     // nReads + 1
+    u32         nReads;
+};
+
+// base `pos` of the read sequence of `strand` (1 = reverse complement)
+__device__ __forceinline__ u32 readBase(const u8 * __restrict__ seq, u32 len, u32 strand, u32 pos)
+{
+    u32 c = strand ? seq[len - 1 - pos] : seq[pos];
+    return (strand && c < 4) ? 3 - c : c;
+}
+
+__host__ __device__ __forceinline__ u32 readErrorsOf(u32 len, float errorRate)
+{
+    u32 e = (u32)((float)len * errorRate);          // reference src/misc_options.h:258-263
+    return e < MAX_ERRORS ? e : MAX_ERRORS;
+}
+__host__ __device__ __forceinline__ u32 readStrataOf(u32 len, float strataRate)
+{
+    u32 s = (u32)((float)len * strataRate);         // reference src/misc_options.h:283-287 (strataCount is never set by the CLI)
+    return s < MAX_ERRORS ? s : MAX_ERRORS;
+}
+// seeds per strand for a given seed-error budget: ceil((e+1)/(E+1)) (reference src/mapper_collector.h:151-155)
+__host__ __device__ __forceinline__ u32 seedCountOf(u32 readErrors, u32 seedErrors) { return (readErrors + 1 + seedErrors) / (seedErrors + 1); }
+
+// ---------------------------------------------------------------------------------------------------
+// Work list: per wave of 64 reads count the reads selected for every bin, scan per bin, scatter (deterministic order).
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_items_count(const u64 * __restrict__ masks, u32 nReads, u32 W, u32 nBins, u32 * __restrict__ waveCounts)
+{
+    const u32 gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const u32 read = gw * 64 + lane;
+    const u32 nWaves = (nReads + 63) / 64;
+    if (gw >= nWaves) return;
+    for (u32 w = 0; w < W; ++w)
+    {
+        u64 m = read < nReads ? masks[(size_t)read * W + w] : 0;
+        // lane j of this pass accumulates bin w*64+j: count lanes whose bit j is set
+        u32 cnt = 0;
+        for (u32 src = 0; src < 64; ++src)
+        {
+            u32 lo = __shfl((u32)m, src, 64), hi = __shfl((u32)(m >> 32), src, 64);
+            u64 ms = ((u64)hi << 32) | lo;
+            cnt += (u32)((ms >> lane) & 1);
+        }
+        u32 bin = w * 64 + lane;
+        if (bin < nBins) waveCounts[(size_t)bin * nWaves + gw] = cnt;
+    }
+}
+
+// one thread per bin: exclusive scan of its row of waveCounts (in place), total into binTotals
+__global__ void k_items_scan_bins(u32 * __restrict__ waveCounts, u32 nWaves, u32 nBins, u32 * __restrict__ binTotals)
+{
+    const u32 bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= nBins) return;
+    u32 * row = waveCounts + (size_t)bin * nWaves;
+    u32 run = 0;
+    for (u32 i = 0; i < nWaves; ++i) { u32 c = row[i]; row[i] = run; run += c; }
+    binTotals[bin] = run;
+}
+
+// single thread: bin starts (exclusive scan) and the bin processing order of sortedBins() — descending load, ties by
+// bin number (reference src/d_mapper.h:843-854; std::sort leaves ties unspecified) — as a rank per bin.
+__global__ void k_items_bin_starts(const u32 * __restrict__ binTotals, u32 nBins, u32 * __restrict__ binStart, u32 * __restrict__ binOrderRank)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    u32 run = 0;
+    for (u32 b = 0; b < nBins; ++b) { binStart[b] = run; run += binTotals[b]; }
+    binStart[nBins] = run;
+    for (u32 b = 0; b < nBins; ++b)
+    {
+        u32 r = 0;
+        for (u32 o = 0; o < nBins; ++o)
+            if (binTotals[o] > binTotals[b] || (binTotals[o] == binTotals[b] && o < b)) ++r;
+        binOrderRank[b] = r;
+    }
+}
+
+__global__ void k_items_scatter(const u64 * __restrict__ masks, u32 nReads, u32 W, u32 nBins, const u32 * __restrict__ waveOffsets,
+                                const u32 * __restrict__ binStart, u32 * __restrict__ itemRead, u16 * __restrict__ itemBin)
+{
+    const u32 gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const u32 read = gw * 64 + lane;
+    const u32 nWaves = (nReads + 63) / 64;
+    if (gw >= nWaves) return;
+    for (u32 w = 0; w < W; ++w)
+    {
+        u64 m = read < nReads ? masks[(size_t)read * W + w] : 0;
+        u64 any = m;
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            u32 lo = __shfl_xor((u32)any, off, 64), hi = __shfl_xor((u32)(any >> 32), off, 64);
+            any |= ((u64)hi << 32) | lo;
+        }
+        while (any)
+        {
+            u32 j = __ffsll((long long)any) - 1;
+            any &= any - 1;
+            u32 bin = w * 64 + j;
+            if (bin >= nBins) continue;
+            bool mine = (m >> j) & 1;
+            u64 b = __ballot(mine);
+            if (mine)
+            {
+                u32 rank = __popcll(b & ((1ull << lane) - 1));
+                u32 dst = binStart[bin] + waveOffsets[(size_t)bin * nWaves + gw] + rank;
+                itemRead[dst] = read;
+                itemBin[dst] = (u16)bin;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2: exact search of the round-0 seeds. One thread per (item, strand, seed slot).
+// hits0[item * 2*S0 + strand*S0 + seedId] = (lo, hi); seedId k covers read offset (count-1-k)*len
+// (seeds are stored in descending offset order, reference src/mapper_collector.h:166-171).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead,
+                                                     const u16 * __restrict__ itemBin, u32 nItems, u32 S0, float errorRate,
+                                                     uint2 * __restrict__ hits0)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 slots = 2 * S0;
+    const u32 item = (u32)(t / slots), slot = (u32)(t % slots);
+    if (item >= nItems) return;
+    const u32 strand = slot / S0, seedId = slot % S0;
+    const u32 read = itemRead[item];
+    const u8 * seq = rd.seqs + rd.offs[read];
+    const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
+    const u32 cnt = seedCountOf(readErrorsOf(len, errorRate), 0);
+    uint2 res = make_uint2(0, 0);
+    if (seedId < cnt && len >= cnt)
+    {
+        const u32 seedLen = len / cnt, off = (cnt - 1 - seedId) * seedLen;
+        BinView b = makeBinView(ix, itemBin[item]);
+        u32 lo = 0, hi = b.n;
+        bool ok = true;
+        for (u32 d = 0; d < seedLen && ok; ++d)
+        {
+            u32 c = readBase(seq, len, strand, off + d);
+            ok = c < 4 && fmStep(b, lo, hi, c);          // N never matches (reference src/index_fm.h:147)
+        }
+        if (ok) res = make_uint2(lo, hi);
+    }
+    hits0[(size_t)item * slots + slot] = res;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bit-parallel prefix edit distance (Myers/Hyyro block algorithm, global start): stands in for SeqAn's
+// Myers<AlignTextBanded<FindPrefix, NMatchesNone_, NMatchesNone_>> as used by find_extender.h:159-168,233-248.
+// Reports, in increasing text end j, every prefix text[0..j) with ed(needle, prefix) <= k (j = 0 too when m <= k).
+// N (code 4) matches nothing.  NW = 64-bit words covering the needle.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, typename TNeedle, typename TText, typename TReport>
+__device__ __forceinline__ void myersPrefixSearch(TNeedle needle, int m, TText text, int t, int k, TReport report)
+{
+    if (m <= k) report(-1, m);
+    if (m == 0)
+    {   // D[0][j] = j
+        for (int j = 1; j <= t && j <= k; ++j) report(j - 1, j);
+        return;
+    }
+    u64 peq[4][NW], vp[NW], vn[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { peq[0][w] = peq[1][w] = peq[2][w] = peq[3][w] = 0; vp[w] = ~0ull; vn[w] = 0; }
+    for (int i = 0; i < m; ++i)
+    {
+        u32 c = needle(i);
+        if (c < 4)
+        {
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if ((i >> 6) == w) { u64 bit = 1ull << (i & 63); if (c == 0) peq[0][w] |= bit; else if (c == 1) peq[1][w] |= bit; else if (c == 2) peq[2][w] |= bit; else peq[3][w] |= bit; }
+        }
+    }
+    const int lastWord = (m - 1) >> 6;
+    const u64 lastBit = 1ull << ((m - 1) & 63);
+    int score = m;
+    const int jmax = t < m + k ? t : m + k;
+    for (int j = 1; j <= jmax; ++j)
+    {
+        u32 c = text(j - 1);
+        int hin = 1;                      // global start: D[0][j] = D[0][j-1] + 1
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+        {
+            if (w <= lastWord)
+            {
+                u64 eq = c == 0 ? peq[0][w] : c == 1 ? peq[1][w] : c == 2 ? peq[2][w] : c == 3 ? peq[3][w] : 0ull;
+                const u64 pv = vp[w], mv = vn[w];
+                const u64 hinNeg = hin < 0 ? 1ull : 0ull;
+                const u64 xv = eq | mv;
+                eq |= hinNeg;
+                const u64 xh = (((eq & pv) + pv) ^ pv) | eq;
+                u64 ph = mv | ~(xh | pv);
+                u64 mh = pv & xh;
+                const u64 top = (w == lastWord) ? lastBit : (1ull << 63);
+                int hout = 0;
+                if (ph & top) hout = 1;
+                if (mh & top) hout = -1;
+                ph <<= 1; mh <<= 1;
+                mh |= hinNeg;
+                if (hin > 0) ph |= 1ull;
+                vp[w] = mh | ~(xv | ph);
+                vn[w] = ph & xv;
+                hin = hout;
+            }
+        }
+        score += hin;
+        if (score <= k) report(j - 1, score);
+    }
+}
+
+struct ItemState
+{
+    u32 minErrors;     // 255 = none yet (ReadsContext::minErrors, reference src/bits_context.h:86)
+    bool mapped;
+};
+
+struct MatchSink
+{
+    RawMatch * pool;
+    u32 *      poolCount;
+    u32        poolCap;
+    u32 *      overflow;
+    u32 *      readMatchCount;
+};
+
+// extend() + _addMatchImpl() for one located seed occurrence (reference src/find_extender.h:262-403, src/mapper_extender.h:293-308).
+template <int NW>
+__device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u32 seedLen, const u8 * __restrict__ seq, u32 len, u32 strand,
+                                 u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
+{
+    const u8 * __restrict__ ctg = b.contigs + b.limits[contig];
+    const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+    const u32 hayEnd = hayBegin + seedLen, needleEnd = needleBegin + seedLen;
+    u32 errors = 0;
+    // _checkSeed: recount against the real contig (Ns were randomised in the index)
+    {
+        u32 d = 0;
+        for (; d < seedLen && errors <= maxErrors; ++d)
+        {
+            u32 h = ctg[hayBegin + d], q = readBase(seq, len, strand, needleBegin + d);
+            errors += !(h == q && h < 4);
+        }
+        if (!(d == seedLen && errors <= maxErrors)) return;
+    }
+    u32 matchBegin = hayBegin;
+    if (needleBegin > 0)
+    {   // _extendLeft on the reversed infixes
+        const u32 leftOffset = needleBegin + (maxErrors - errors);
+        const u32 leftBegin = hayBegin > leftOffset ? hayBegin - leftOffset : 0;
+        const int hayLen = (int)(hayBegin - leftBegin), ndlLen = (int)needleBegin;
+        int lcp = 0;
+        while (lcp < hayLen && lcp < ndlLen)
+        {
+            u32 h = ctg[hayBegin - 1 - lcp], q = readBase(seq, len, strand, needleBegin - 1 - lcp);
+            if (!(h == q && h < 4)) break;
+            ++lcp;
+        }
+        if (lcp == ndlLen)
+            matchBegin -= lcp;
+        else
+        {
+            const u32 remaining = maxErrors - errors;
+            if (!remaining) return;
+            u32 minErr = remaining + 1;
+            int endPos = 0;
+            const u32 hb = hayBegin - 1 - lcp, nb = needleBegin - 1 - lcp;
+            myersPrefixSearch<NW>([&](int i) { return readBase(seq, len, strand, nb - i); }, ndlLen - lcp,
+                                  [&](int j) { return (u32)ctg[hb - j]; }, hayLen - lcp, (int)remaining,
+                                  [&](int pos, int dist) { if ((u32)dist <= minErr) { minErr = (u32)dist; endPos = pos + 1; } });
+            errors += minErr;
+            matchBegin -= (u32)(endPos + lcp);
+            if (errors > maxErrors) return;
+        }
+    }
+    u32 matchEnd = hayEnd;
+    if (needleEnd < len)
+    {   // _extendRight, last base held out
+        const u32 rightOffset = len - needleBegin + (maxErrors - errors);
+        u32 rightEnd = clen;
+        if (rightEnd > hayBegin + rightOffset) rightEnd = hayBegin + rightOffset;
+        const int hayLen = (int)(rightEnd - hayEnd), ndlLen = (int)(len - needleEnd);
+        int lcp = 0;
+        while (lcp < hayLen && lcp < ndlLen)
+        {
+            u32 h = ctg[hayEnd + lcp], q = readBase(seq, len, strand, needleEnd + lcp);
+            if (!(h == q && h < 4)) break;
+            ++lcp;
+        }
+        if (lcp == ndlLen)
+            matchEnd += lcp;
+        else if (lcp == hayLen)
+        {
+            errors += (u32)(ndlLen - hayLen);
+            matchEnd += lcp;
+            if (errors > maxErrors) return;
+        }
+        else
+        {
+            const u32 remaining = maxErrors - errors;
+            if (!remaining) return;
+            u32 minErr = remaining + 1;
+            int endPos = 0;
+            const u32 hb = hayEnd + lcp, nb = needleEnd + lcp;
+            const int hl = hayLen - lcp, nl = ndlLen - lcp;
+            const u32 lastNeedle = readBase(seq, len, strand, nb + nl - 1);
+            myersPrefixSearch<NW>([&](int i) { return readBase(seq, len, strand, nb + i); }, nl - 1,
+                                  [&](int j) { return (u32)ctg[hb + j]; }, hl - 1, (int)remaining,
+                                  [&](int pos, int dist) {
+                                      const int currentEnd = pos + 1;
+                                      u32 cur = (u32)dist;
+                                      const u32 h = ctg[hb + currentEnd];
+                                      if (!(h == lastNeedle && h < 4))
+                                          if (++cur > remaining) return;
+                                      if (cur <= minErr) { minErr = cur; endPos = currentEnd; }
+                                  });
+            errors += minErr;
+            matchEnd += (u32)(endPos + lcp + 1);
+            if (errors > maxErrors) return;
+        }
+    }
+    // _addMatchImpl
+    const u32 slot = atomicAdd(sink.poolCount, 1u);
+    if (slot < sink.poolCap)
+    {
+        RawMatch m;
+        m.read = read; m.begin = matchBegin; m.len = (u16)(matchEnd - matchBegin); m.errors = (u8)errors; m.strand = (u8)strand;
+        m.bin = (u16)bin; m.contig = (u16)contig;
+        sink.pool[slot] = m;
+        atomicAdd(&sink.readMatchCount[read], 1u);
+    }
+    else
+        atomicExch(sink.overflow, 1u);
+    if (errors < st.minErrors) st.minErrors = errors;
+}
+
+// _extendHitImpl: every SA position of one hit range (reference src/mapper_extender.h:215-286)
+template <int NW>
+__device__ void extendRange(const BinView & b, u32 lo, u32 hi, u32 seedLen, const u8 * __restrict__ seq, u32 len, u32 strand,
+                            u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
+{
+    for (u32 row = lo; row < hi; ++row)
+    {
+        u32 contig, x;
+        fmLocate(b, row, contig, x);
+        const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+        if (clen - x < seedLen) continue;                       // suffixLength < seedLength
+        extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, seq, len, strand, needleBegin, maxErrors, read, bin, st, sink);
+    }
+}
+
+// Hamming backtracking over the FM trie with at most maxErr substitutions (SeqAn find(..., Backtracking<HammingDistance>),
+// SURVEY.md C.1): calls leaf(lo, hi) for every leaf (any error count <= maxErr). Depth-first with one frame per error spent.
+template <typename TLeaf>
+__device__ void fmBacktrack(const BinView & b, const u8 * __restrict__ seq, u32 len, u32 strand, u32 off, u32 seedLen, u32 maxErr, TLeaf leaf)
+{
+    struct Frame { u32 lo, hi, d, alt; };
+    Frame st[3];
+    int level = 0;
+    st[0].lo = 0; st[0].hi = b.n; st[0].d = 0; st[0].alt = 0;
+    while (level >= 0)
+    {
+        Frame & f = st[level];
+        if (f.d == seedLen) { leaf(f.lo, f.hi); --level; continue; }
+        const u32 sc = readBase(seq, len, strand, off + f.d);
+        if ((u32)level < maxErr && f.alt < 4)
+        {
+            const u32 c = f.alt++;
+            if (c == sc) continue;
+            u32 lo = f.lo, hi = f.hi;
+            if (fmStep(b, lo, hi, c))
+            {
+                ++level;
+                st[level].lo = lo; st[level].hi = hi; st[level].d = f.d + 1; st[level].alt = 0;
+            }
+            continue;
+        }
+        // advance along the seed's own character
+        if (sc > 3) { --level; continue; }
+        u32 lo = f.lo, hi = f.hi;
+        if (!fmStep(b, lo, hi, sc)) { --level; continue; }
+        f.lo = lo; f.hi = hi; f.d += 1; f.alt = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: one thread per work item runs the read-local remainder of _mapReadsImpl.
+// ---------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
+                                                u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
+                                                u32 * __restrict__ hardItems)
+{
+    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= nItems) return;
+    const u32 read = itemRead[item], bin = itemBin[item];
+    const u8 * seq = rd.seqs + rd.offs[read];
+    const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
+    const u32 readErrors = readErrorsOf(len, prm.errorRate), readStrata = readStrataOf(len, prm.strataRate);
+    const BinView b = makeBinView(ix, bin);
+    ItemState st; st.minErrors = 255; st.mapped = false;
+    const uint2 * h0 = hits0 + (size_t)item * 2 * S0;
+
+    // ---- classifyReads (reference src/mapper_classifier.h:111-155)
+    const u32 cnt0 = seedCountOf(readErrors, 0);
+    u64 total = 0;
+    for (u32 s = 0; s < 2 * S0; ++s) total += h0[s].y - h0[s].x;
+    u32 seedErrors = 0;
+    if (total > prm.hitsThreshold) seedErrors = (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
+
+    if (seedErrors == 0)
+    {
+        // ---- rankSeeds + extendHits<0>(bucket 0): seeds by ascending hit count, ties keep ascending seed id
+        if (len >= cnt0)
+        {
+            const u32 seedLen = len / cnt0;
+            u32 done[2] = {0, 0};   // bitmask of seeds already taken per strand (cnt0 <= 32)
+            for (u32 rank = 0; rank < cnt0 && !st.mapped; ++rank)
+            {
+                for (u32 strand = 0; strand < 2; ++strand)
+                {
+                    u32 best = 0xFFFFFFFFu, bestId = 0;
+                    for (u32 k = 0; k < cnt0; ++k)
+                    {
+                        if (done[strand] >> k & 1) continue;
+                        uint2 r = h0[strand * S0 + k];
+                        u32 c = r.y - r.x;
+                        if (c < best) { best = c; bestId = k; }
+                    }
+                    done[strand] |= 1u << bestId;
+                    uint2 r = h0[strand * S0 + bestId];
+                    extendRange<NW>(b, r.x, r.y, seedLen, seq, len, strand, (cnt0 - 1 - bestId) * seedLen, readErrors, read, bin, st, sink);
+                }
+                if (st.minErrors + readStrata <= rank) st.mapped = true;     // seedErrors = 0: rank * (0 + 1)
+            }
+        }
+        return;
+    }
+
+    // ---- hard read: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2)
+    atomicAdd(hardItems, 1u);
+    const u32 cntB = seedCountOf(readErrors, seedErrors);
+    if (len < cntB) return;
+    const u32 seedLen = len / cntB;
+    // rounds: E = 0 (exact search of the long seeds), 1, and 2 (only bucket 2, only above LOW sensitivity)
+    for (u32 E = 0; E <= 2 && !st.mapped; ++E)
+    {
+        if (E > seedErrors) break;
+        if (E == 2 && prm.sensitivity == 0) break;
+        // per-seed hit counts (findSeeds<E> + rankSeeds)
+        u32 counts[2][MAX_SEEDS];
+        for (u32 strand = 0; strand < 2; ++strand)
+            for (u32 k = 0; k < cntB; ++k)
+            {
+                u32 c = 0;
+                fmBacktrack(b, seq, len, strand, (cntB - 1 - k) * seedLen, seedLen, E, [&](u32 lo, u32 hi) { c += hi - lo; });
+                counts[strand][k] = c;
+            }
+        u32 done[2] = {0, 0};
+        for (u32 rank = 0; rank < cntB && !st.mapped; ++rank)
+        {
+            for (u32 strand = 0; strand < 2; ++strand)
+            {
+                u32 best = 0xFFFFFFFFu, bestId = 0;
+                for (u32 k = 0; k < cntB; ++k)
+                {
+                    if (done[strand] >> k & 1) continue;
+                    if (counts[strand][k] < best) { best = counts[strand][k]; bestId = k; }
+                }
+                done[strand] |= 1u << bestId;
+                const u32 off = (cntB - 1 - bestId) * seedLen;
+                fmBacktrack(b, seq, len, strand, off, seedLen, E, [&](u32 lo, u32 hi) {
+                    extendRange<NW>(b, lo, hi, seedLen, seq, len, strand, off, readErrors, read, bin, st, sink);
+                });
+            }
+            if (st.minErrors + readStrata <= rank * (E + 1)) st.mapped = true;
+        }
+    }
+}
+
+} // namespace dy

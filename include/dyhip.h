@@ -1,0 +1,163 @@
+/*
+ * dyhip.h — C ABI of libdyhip.so, the MI355X (gfx950) implementation of DREAM-Yara's mapping hot path.
+ *
+ * The reference (temehi/dream_yara, /root/reference) has no FFI: its hot path sits behind C++ template
+ * calls inside one process.  Each entry point below replaces one of those internal interfaces; the
+ * reference file:line it stands in for is given per function.  Conventions: plain C types only, the caller
+ * owns every buffer it passes, the library owns handles until the matching *_free; every function returns
+ * DY_OK (0) or a negative DY_E* code and dy_last_error() gives the message; no exception crosses the ABI.
+ * One host thread drives a context at a time.  There is NO CPU fallback: without a HIP device every
+ * compute entry point fails with DY_ENODEVICE.
+ */
+#ifndef DYHIP_H_
+#define DYHIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DY_ABI_VERSION 1
+
+enum {
+    DY_OK = 0,
+    DY_EINVAL = -1,      /* bad argument */
+    DY_EIO = -2,         /* file could not be read / written / parsed */
+    DY_ENODEVICE = -3,   /* no usable HIP device */
+    DY_EHIP = -4,        /* a HIP runtime call failed */
+    DY_ENOMEM = -5,
+    DY_EUNSUPPORTED = -6 /* valid for the reference, not implemented here (say which in dy_last_error) */
+};
+
+typedef struct dy_ctx   dy_ctx;    /* device, stream, workspaces */
+typedef struct dy_ibf   dy_ibf;    /* Interleaved Bloom filter resident in HBM */
+typedef struct dy_index dy_index;  /* all bins' FM indices + contigs resident in HBM */
+typedef struct dy_reads dy_reads;  /* one batch of reads resident in HBM */
+typedef struct dy_result dy_result;/* per-read results of one batch, resident in HBM + host mirror */
+
+/* ---- library / context ------------------------------------------------------------------------------- */
+int         dy_abi_version(void);
+const char *dy_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int         dy_device_count(void);
+/* Creates a context on `device` (ordinal among visible devices).  Replaces configureThreads()
+ * (reference src/mapper.h:349-355): the "thread pool" of this implementation is one GPU + one stream. */
+int         dy_ctx_create(int device, dy_ctx **out);
+void        dy_ctx_free(dy_ctx *ctx);
+/* Blocks until all work queued on the context's stream has finished. */
+int         dy_ctx_sync(dy_ctx *ctx);
+/* Returns the context's hipStream_t as an opaque pointer (for event timing by the caller). */
+void       *dy_ctx_stream(dy_ctx *ctx);
+
+/* ---- Interleaved Bloom filter ------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t n_bits;        /* including the 256-bit trailer */
+    uint32_t n_bins;
+    uint32_t n_hashes;
+    uint32_t kmer_size;
+    uint32_t words_per_pos; /* W = ceil(bins/64) */
+    uint64_t n_hash_pos;    /* (bits-256)/(64 W) */
+} dy_ibf_info;
+
+/* SeqAnBloomFilter(const char*) load constructor — reference src/d_bloom_filter.h:79-89 (+ _getMetadata :255-265). */
+int  dy_ibf_load(dy_ctx *ctx, const char *path, dy_ibf **out);
+/* SeqAnBloomFilter(n_bins, n_hash, k, vec_size) — reference src/d_bloom_filter.h:48-58. n_bits includes the trailer. */
+int  dy_ibf_create(dy_ctx *ctx, uint32_t n_bins, uint32_t n_hashes, uint32_t kmer_size, uint64_t n_bits, dy_ibf **out);
+/* addKmers(text, binNo) — reference src/d_bloom_filter.h:91-94,293-315. `seq` = Dna5 codes (A0 C1 G2 T3 N4), host memory. */
+int  dy_ibf_add(dy_ibf *f, const uint8_t *seq, uint64_t len, uint32_t bin);
+/* save() — reference src/d_bloom_filter.h:150-154 (sdsl bit_vector file with the metadata trailer). */
+int  dy_ibf_save(dy_ibf *f, const char *path);
+int  dy_ibf_get_info(const dy_ibf *f, dy_ibf_info *info);
+void dy_ibf_free(dy_ibf *f);
+/* DisOptions::getThreshold — reference src/d_mapper.h:83-92.  error_rate is the float the CLI stores (e/100.0). */
+uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len);
+
+/* ---- reads ------------------------------------------------------------------------------------------- */
+/* Uploads a batch: `seqs` = concatenated Dna5 codes of the FORWARD reads, `offs` = n_reads+1 offsets.
+ * The reverse complements (reference src/store_seqs.h:271-290, appendReverseComplement) are derived on the device.
+ * Limits: n_reads <= 2097151 (21-bit read id, reference src/bits_matches.h:179-183), read length <= 8191 (:211-215). */
+int  dy_reads_upload(dy_ctx *ctx, const uint8_t *seqs, const uint64_t *offs, uint32_t n_reads, dy_reads **out);
+uint32_t dy_reads_count(const dy_reads *r);
+void dy_reads_free(dy_reads *r);
+
+/* clasifyLoadedReads — reference src/d_mapper.h:309-387 with whichBins — src/d_bloom_filter.h:161-224 (kernel K1).
+ * For every read ORs whichBins(fwd) and whichBins(revcomp) into W 64-bit words (bin b = bit b%64 of word b/64).
+ * bin_masks_host (n_reads*W words, may be NULL) receives a copy; the masks also stay on the device for dy_map_reads.
+ * threshold 0 reproduces the reference's "every read to every bin" (src/d_mapper.h:320-333) without the duplicate pass. */
+int  dy_ibf_query(dy_ibf *f, dy_reads *reads, uint16_t threshold, uint64_t *bin_masks_host);
+
+/* ---- index ------------------------------------------------------------------------------------------- */
+/* loadContigs + loadContigsIndex for every bin — reference src/mapper.h:362-403, src/index_fm.h:84-103,
+ * src/store_seqs.h:128-141.  Reads <dir>/<b>.{txt.size,txt.limits,txt.concat,rid.limits,rid.concat,sa.len,sa.ind,
+ * sa.val,lf.pst,lf.drv,lf.drs,lf.drp} for b in [0,n_bins) and uploads them. */
+int  dy_index_load(dy_ctx *ctx, const char *dir, uint32_t n_bins, dy_index **out);
+uint32_t dy_index_bins(const dy_index *idx);
+uint32_t dy_index_contigs(const dy_index *idx);                       /* over all bins */
+const char *dy_index_contig_name(const dy_index *idx, uint32_t c);    /* global contig id, bin order */
+uint64_t dy_index_contig_length(const dy_index *idx, uint32_t c);
+void dy_index_free(dy_index *idx);
+
+/* ---- mapping ----------------------------------------------------------------------------------------- */
+typedef struct {
+    float    error_rate;      /* Options::errorRate  (reference src/mapper.h:68,99)  */
+    float    strata_rate;     /* Options::strataRate (:70,101) */
+    uint32_t sensitivity;     /* 0 low, 1 high (2 = full/edit-distance seeds: DY_EUNSUPPORTED) (:72,103) */
+    uint32_t hits_threshold;  /* Options::hitsThreshold (:84,111), default 300 */
+    uint32_t use_filter;      /* 0 = -ft none: every read goes to every bin (reference src/d_mapper.h:399-405) */
+    uint32_t reserved;
+} dy_params;
+void dy_params_default(dy_params *p);
+
+/* One match, unpacked from the reference's bit-field (src/bits_matches.h:116-127). */
+typedef struct {
+    uint32_t contig;        /* global contig id (bin offset applied, reference src/d_mapper.h:146) */
+    uint32_t begin;         /* 0-based */
+    uint16_t length;        /* the reference's 13-bit contigEnd member */
+    uint8_t  errors;
+    uint8_t  is_rev;
+} dy_match;
+
+/* Per-read record: what MatchesWriter consumes (reference src/mapper_writer.h:296-345). */
+typedef struct {
+    dy_match primary;       /* valid iff mapped */
+    uint32_t mapped;
+    uint32_t best_count;    /* X0 */
+    uint32_t sub_count;     /* X1 */
+    uint32_t mapq;
+    uint32_t set_begin;     /* [set_begin, set_begin+best_count+sub_count) in dy_result_matches(): matchesSet[read] */
+    uint32_t cigar_begin;   /* [cigar_begin, cigar_begin+cigar_len) in dy_result_cigars() */
+    uint32_t cigar_len;
+} dy_read_result;
+
+/* runDisMapper's per-batch body — reference src/d_mapper.h:874-886: for every bin selected by the masks left on
+ * `reads` by dy_ibf_query run _mapReadsImpl (:252-303: seeds, FM search K2, classify, rank, locate+extend K3,
+ * aggregate, rank, align primaries), then finalizeMainMapper (:828-838: aggregate, rankMatches2, cigar transfer).
+ * Everything runs on the device; the call returns after the results are also mirrored on the host. */
+int  dy_map_reads(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, dy_result **out);
+/* Same, but asynchronous: results stay on the device until dy_result_fetch(). Used for timing the hot path. */
+int  dy_map_reads_async(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, dy_result **out);
+int  dy_result_fetch(dy_result *r);
+const dy_read_result *dy_result_reads(const dy_result *r);     /* n_reads entries */
+const dy_match       *dy_result_matches(const dy_result *r);   /* matchesSet of all reads back to back */
+uint64_t              dy_result_n_matches(const dy_result *r);
+/* CIGAR ops packed as (count << 4) | op with op 0=M 1=I 2=D (BAM numbering). */
+const uint32_t       *dy_result_cigars(const dy_result *r);
+void dy_result_free(dy_result *r);
+
+/* Stage counters of the last dy_map_reads call (observability; mirrors Stats, reference src/mapper.h:238-279). */
+typedef struct {
+    uint64_t items;          /* (read,bin) pairs = filteredReads (reference src/d_mapper.h:442) */
+    uint64_t raw_matches;    /* extension results before compaction */
+    uint64_t hard_items;     /* items re-seeded by classifyReads */
+    uint64_t pool_retries;   /* times the match pool had to grow */
+    double   ms_ibf;         /* K1 of the last dy_ibf_query on this context (hipEvent on the context's stream) */
+    double   ms_items, ms_search, ms_extend, ms_finalize;   /* device time per stage of the last dy_map_reads */
+} dy_map_stats;
+int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYHIP_H_ */
