@@ -1,0 +1,280 @@
+"""dream_yara_amd — Python binding of libdyhip.so (C ABI in include/dyhip.h).
+
+This is the thin host-side mirror used by the tests and by bench.py: every call goes straight through ctypes into the
+gfx950 library.  There is no Python or CPU implementation of the mapping path here; if the shared library has not been
+built (python -m dream_yara_amd.build) or no HIP device is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdyhip.so")
+
+DY_OK = 0
+DY_ENODEVICE = -3
+
+
+class DyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libdyhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IbfInfo(C.Structure):
+    _fields_ = [("n_bits", C.c_uint64), ("n_bins", C.c_uint32), ("n_hashes", C.c_uint32), ("kmer_size", C.c_uint32),
+                ("words_per_pos", C.c_uint32), ("n_hash_pos", C.c_uint64)]
+
+
+class Params(C.Structure):
+    _fields_ = [("error_rate", C.c_float), ("strata_rate", C.c_float), ("sensitivity", C.c_uint32),
+                ("hits_threshold", C.c_uint32), ("use_filter", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Match(C.Structure):
+    _fields_ = [("contig", C.c_uint32), ("begin", C.c_uint32), ("length", C.c_uint16), ("errors", C.c_uint8),
+                ("is_rev", C.c_uint8)]
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("primary", Match), ("mapped", C.c_uint32), ("best_count", C.c_uint32), ("sub_count", C.c_uint32),
+                ("mapq", C.c_uint32), ("set_begin", C.c_uint32), ("cigar_begin", C.c_uint32), ("cigar_len", C.c_uint32)]
+
+
+class MapStats(C.Structure):
+    _fields_ = [("items", C.c_uint64), ("raw_matches", C.c_uint64), ("hard_items", C.c_uint64), ("pool_retries", C.c_uint64),
+                ("ms_ibf", C.c_double), ("ms_items", C.c_double), ("ms_search", C.c_double), ("ms_extend", C.c_double),
+                ("ms_finalize", C.c_double)]
+
+
+MATCH_DTYPE = np.dtype([("contig", "<u4"), ("begin", "<u4"), ("length", "<u2"), ("errors", "u1"), ("is_rev", "u1")])
+READ_RESULT_DTYPE = np.dtype([("primary", MATCH_DTYPE), ("mapped", "<u4"), ("best_count", "<u4"), ("sub_count", "<u4"),
+                              ("mapq", "<u4"), ("set_begin", "<u4"), ("cigar_begin", "<u4"), ("cigar_len", "<u4")])
+
+# every symbol include/dyhip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("dy_abi_version", C.c_int, []),
+    ("dy_last_error", C.c_char_p, []),
+    ("dy_device_count", C.c_int, []),
+    ("dy_ctx_create", C.c_int, [C.c_int, C.POINTER(_P)]),
+    ("dy_ctx_free", None, [_P]),
+    ("dy_ctx_sync", C.c_int, [_P]),
+    ("dy_ctx_stream", _P, [_P]),
+    ("dy_ibf_load", C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
+    ("dy_ibf_create", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
+    ("dy_ibf_add", C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
+    ("dy_ibf_save", C.c_int, [_P, C.c_char_p]),
+    ("dy_ibf_get_info", C.c_int, [_P, C.POINTER(IbfInfo)]),
+    ("dy_ibf_free", None, [_P]),
+    ("dy_ibf_threshold", C.c_uint16, [C.c_float, C.c_uint32, C.c_uint16]),
+    ("dy_reads_upload", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
+    ("dy_reads_count", C.c_uint32, [_P]),
+    ("dy_reads_free", None, [_P]),
+    ("dy_ibf_query", C.c_int, [_P, _P, C.c_uint16, _P]),
+    ("dy_index_load", C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(_P)]),
+    ("dy_index_bins", C.c_uint32, [_P]),
+    ("dy_index_contigs", C.c_uint32, [_P]),
+    ("dy_index_contig_name", C.c_char_p, [_P, C.c_uint32]),
+    ("dy_index_contig_length", C.c_uint64, [_P, C.c_uint32]),
+    ("dy_index_free", None, [_P]),
+    ("dy_params_default", None, [C.POINTER(Params)]),
+    ("dy_map_reads", C.c_int, [_P, _P, _P, C.POINTER(Params), C.POINTER(_P)]),
+    ("dy_map_reads_async", C.c_int, [_P, _P, _P, C.POINTER(Params), C.POINTER(_P)]),
+    ("dy_result_fetch", C.c_int, [_P]),
+    ("dy_result_reads", _P, [_P]),
+    ("dy_result_matches", _P, [_P]),
+    ("dy_result_n_matches", C.c_uint64, [_P]),
+    ("dy_result_cigars", _P, [_P]),
+    ("dy_result_free", None, [_P]),
+    ("dy_map_get_stats", C.c_int, [_P, C.POINTER(MapStats)]),
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libdyhip.so and binds every declared symbol. Raises if the library is missing: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libdyhip.so is not built (%s); run: python -m dream_yara_amd.build" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the ABI and the header drifted apart
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != DY_OK:
+        raise DyError(rc, load_library().dy_last_error().decode(errors="replace"))
+
+
+def device_count():
+    return load_library().dy_device_count()
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _P()
+        _check(self.lib.dy_ctx_create(device, C.byref(h)))
+        self.h = h
+
+    def sync(self):
+        _check(self.lib.dy_ctx_sync(self.h))
+
+    def stats(self):
+        s = MapStats()
+        _check(self.lib.dy_map_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in MapStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.lib.dy_ctx_free(self.h)
+            self.h = None
+
+
+class Ibf:
+    """Interleaved Bloom filter in HBM (reference src/d_bloom_filter.h, class SeqAnBloomFilter)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.lib, self.h = ctx, ctx.lib, handle
+
+    @classmethod
+    def load(cls, ctx, path):
+        h = _P()
+        _check(ctx.lib.dy_ibf_load(ctx.h, os.fsencode(path), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def create(cls, ctx, n_bins, n_hashes, kmer_size, n_bits):
+        h = _P()
+        _check(ctx.lib.dy_ibf_create(ctx.h, n_bins, n_hashes, kmer_size, n_bits, C.byref(h)))
+        return cls(ctx, h)
+
+    def add(self, codes, bin_no):
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        _check(self.lib.dy_ibf_add(self.h, codes.ctypes.data, codes.size, bin_no))
+
+    def save(self, path):
+        _check(self.lib.dy_ibf_save(self.h, os.fsencode(path)))
+
+    def info(self):
+        i = IbfInfo()
+        _check(self.lib.dy_ibf_get_info(self.h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in IbfInfo._fields_}
+
+    def query(self, reads, threshold, want_masks=True):
+        """whichBins(fwd) | whichBins(revcomp) per read -> (n_reads, W) uint64 (or None)."""
+        W = self.info()["words_per_pos"]
+        masks = np.empty((reads.n, W), dtype=np.uint64) if want_masks else None
+        _check(self.lib.dy_ibf_query(self.h, reads.h, threshold, masks.ctypes.data if want_masks else None))
+        return masks
+
+    def close(self):
+        if self.h:
+            self.lib.dy_ibf_free(self.h)
+            self.h = None
+
+
+def threshold(error_rate, kmer_size, read_len):
+    return load_library().dy_ibf_threshold(np.float32(error_rate), kmer_size, read_len)
+
+
+class Reads:
+    def __init__(self, ctx, codes, offs):
+        self.ctx, self.lib = ctx, ctx.lib
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        self.n = offs.size - 1
+        h = _P()
+        _check(self.lib.dy_reads_upload(ctx.h, codes.ctypes.data, offs.ctypes.data, self.n, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.dy_reads_free(self.h)
+            self.h = None
+
+
+class Index:
+    def __init__(self, ctx, directory, n_bins):
+        self.ctx, self.lib = ctx, ctx.lib
+        h = _P()
+        _check(self.lib.dy_index_load(ctx.h, os.fsencode(directory), n_bins, C.byref(h)))
+        self.h = h
+
+    def contig_names(self):
+        return [self.lib.dy_index_contig_name(self.h, c).decode() for c in range(self.lib.dy_index_contigs(self.h))]
+
+    def contig_lengths(self):
+        return [self.lib.dy_index_contig_length(self.h, c) for c in range(self.lib.dy_index_contigs(self.h))]
+
+    def close(self):
+        if self.h:
+            self.lib.dy_index_free(self.h)
+            self.h = None
+
+
+def default_params(**kw):
+    p = Params()
+    load_library().dy_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Result:
+    def __init__(self, ctx, handle, n_reads):
+        self.ctx, self.lib, self.h, self.n = ctx, ctx.lib, handle, n_reads
+
+    def fetch(self):
+        _check(self.lib.dy_result_fetch(self.h))
+        return self
+
+    def reads(self):
+        ptr = self.lib.dy_result_reads(self.h)
+        if not ptr or not self.n:
+            return np.zeros(0, dtype=READ_RESULT_DTYPE)
+        buf = (C.c_char * (self.n * READ_RESULT_DTYPE.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=READ_RESULT_DTYPE).copy()
+
+    def matches(self):
+        n = self.lib.dy_result_n_matches(self.h)
+        ptr = self.lib.dy_result_matches(self.h)
+        if not ptr or not n:
+            return np.zeros(0, dtype=MATCH_DTYPE)
+        buf = (C.c_char * (n * MATCH_DTYPE.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=MATCH_DTYPE).copy()
+
+    def cigars(self):
+        rr = self.reads()
+        n = int((rr["cigar_begin"] + rr["cigar_len"]).max()) if rr.size else 0
+        ptr = self.lib.dy_result_cigars(self.h)
+        if not ptr or not n:
+            return np.zeros(0, dtype=np.uint32)
+        buf = (C.c_char * (n * 4)).from_address(ptr)
+        return np.frombuffer(buf, dtype=np.uint32).copy()
+
+    def close(self):
+        if self.h:
+            self.lib.dy_result_free(self.h)
+            self.h = None
+
+
+def map_reads(ctx, index, reads, params, asynchronous=False):
+    """runDisMapper's per-batch body on the device (reference src/d_mapper.h:874-886)."""
+    h = _P()
+    fn = ctx.lib.dy_map_reads_async if asynchronous else ctx.lib.dy_map_reads
+    _check(fn(ctx.h, index.h, reads.h, C.byref(params), C.byref(h)))
+    return Result(ctx, h, reads.n)
+
+
+def cigar_string(ops):
+    return "".join("%d%s" % (int(o) >> 4, "MID"[int(o) & 15]) for o in ops)

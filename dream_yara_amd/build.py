@@ -40,7 +40,8 @@ def _run(cmd):
 
 def build(force=False):
     srcs = _sources()
-    if force or not _newer(LIB, srcs):
+    lib_srcs = [s for s in srcs if not s.endswith(".cpp")]
+    if force or not _newer(LIB, lib_srcs):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB,
               os.path.join(CSRC, "dyhip.hip")])
     for tool in ("dream_yara_mapper", "dream_yara_build_filter", "dream_yara_indexer"):
@@ -48,8 +49,9 @@ def build(force=False):
         exe = os.path.join(CSRC, tool)
         if not os.path.exists(src):
             continue
-        if force or not _newer(exe, srcs + [LIB]):
-            _run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, src, "-L" + CSRC, "-ldyhip", "-Wl,-rpath,$ORIGIN"])
+        if force or not _newer(exe, [src, LIB] + [s for s in srcs if s.endswith((".h", ".hpp"))]):
+            link = [] if tool == "dream_yara_indexer" else ["-L" + CSRC, "-ldyhip", "-Wl,-rpath,$ORIGIN"]
+            _run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, src] + link)
     return LIB
 
 

@@ -96,8 +96,6 @@ __device__ __forceinline__ bool lessErrors(const RawMatch & a, u32 ia, const Raw
     return lessBegin(a, ia, b, ib);
 }
 
-enum { AUX_FIRST_END = 1, AUX_U2 = 2, AUX_TAIL1 = 4, AUX_TAIL2 = 8, AUX_PRIMARY = 16 };
-
 __device__ __forceinline__ void waveFence()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -105,8 +103,62 @@ __device__ __forceinline__ void waveFence()
 }
 
 __device__ __forceinline__ u32 waveMin32(u32 v) { for (int o = 32; o >= 1; o >>= 1) { u32 t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
-__device__ __forceinline__ u32 waveMax32(u32 v) { for (int o = 32; o >= 1; o >>= 1) { u32 t = __shfl_xor(v, o, 64); v = t > v ? t : v; } return v; }
 __device__ __forceinline__ u32 waveSum32(u32 v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+
+// Sorts idx[0..cnt) (indices into some element array) ascending under the strict total order `less(ia, ib)`.
+// Bitonic network with all compare-exchanges ascending (partner i ^ (k-1) on the first step of each merge), which is
+// valid for any cnt: positions >= cnt behave as +infinity and never move.  One wavefront, idx in global memory.
+template <typename TLess>
+__device__ void waveSort(u32 * idx, u32 cnt, u32 lane, TLess less)
+{
+    if (cnt <= 1) return;
+    if (cnt <= 64)
+    {   // in registers: lane p holds position p
+        const u32 INF = 0xFFFFFFFFu;
+        u32 mine = lane < cnt ? idx[lane] : INF;
+        for (u32 k = 2; (k >> 1) < cnt; k <<= 1)
+        {
+            for (u32 j = k >> 1, first = 1; j > 0; j >>= 1, first = 0)
+            {
+                const u32 partner = first ? (lane ^ (k - 1)) : (lane ^ j);
+                const u32 other = __shfl(mine, partner, 64);
+                const bool iAmLow = lane < partner;
+                // ascending: low position keeps the smaller
+                bool otherLess = other != INF && (mine == INF || less(other, mine));
+                bool mineLess = mine != INF && (other == INF || less(mine, other));
+                if (iAmLow ? otherLess : mineLess) mine = other;
+            }
+        }
+        if (lane < cnt) idx[lane] = mine;
+        waveFence();
+        return;
+    }
+    for (u32 k = 2; (k >> 1) < cnt; k <<= 1)
+    {
+        for (u32 j = k >> 1, first = 1; j > 0; j >>= 1, first = 0)
+        {
+            for (u32 i = lane; i < cnt; i += 64)
+            {
+                const u32 l = first ? (i ^ (k - 1)) : (i ^ j);
+                if (l > i && l < cnt)
+                {
+                    const u32 a = idx[i], b = idx[l];
+                    if (less(b, a)) { idx[i] = b; idx[l] = a; }
+                }
+            }
+            waveFence();
+        }
+    }
+}
+
+// wave-wide stream compaction helper: returns the slot of this lane's item (valid only if pred) and advances base
+__device__ __forceinline__ u32 wavePush(bool pred, u32 lane, u32 & base)
+{
+    const u64 b = __ballot(pred);
+    const u32 slot = base + (u32)__popcll(b & ((1ull << lane) - 1));
+    base += (u32)__popcll(b);
+    return slot;
+}
 
 // Banded affine alignment of one match (contig horizontal, read vertical, free contig end gaps) + traceback.
 // Mirrors globalAlignment(..., Score<int>(0,-1000,-999,-1001), AlignConfig<true,false,false,true>, -e, +e, Gotoh) followed by
@@ -208,8 +260,6 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
     const u32 lane = threadIdx.x & 63;
     const u32 gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 nWaves = (gridDim.x * blockDim.x) >> 6;
-    __shared__ u32 sCount[4];
-    u32 & mCount = sCount[threadIdx.x >> 6];
     u8 * dp = A.dpScratch + (size_t)gwave * A.dpStride;
 
     for (u32 read = gwave; read < A.nReads; read += nWaves)
@@ -219,188 +269,189 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
         const u8 * seq = A.readSeqs + A.readOffs[read];
         ReadOut ro; ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
         ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
-        if (lane == 0) A.out[read] = ro;
-        if (n == 0) continue;
+        if (n == 0) { if (lane == 0) A.out[read] = ro; continue; }
         const RawMatch * E = A.gp + s0;
-        u32 * aux = A.aux + (size_t)4 * s0;            // [0]=flags [1]=idxA [2]=posB [3]=unused
-        RawMatch * M = A.marr + (size_t)3 * s0;
-        u32 * maux = A.maux + (size_t)6 * s0;
+        u32 * idxA = A.aux + (size_t)4 * s0;           // n entries: all matches of the read in child END order
+        u32 * idxB = idxA + n;                         // <= n entries: pass-1 survivors of the current bin
+        RawMatch * M = A.marr + (size_t)3 * s0;        // the main mapper's matchesByCoord of this read
+        u32 * idxM = A.maux + (size_t)6 * s0;          // 3n
+        u32 * idxF = idxM + (size_t)3 * n;             // 3n
 
-        // ---- pass A: child END pass — within-bin rank and "first of its (contig,strand,end) group"
-        for (u32 i = lane; i < n; i += 64)
-        {
-            const RawMatch a = E[i];
-            u32 idxA = 0; bool first = true;
-            for (u32 j = 0; j < n; ++j)
-            {
-                const RawMatch b = E[j];
-                if (b.bin != a.bin || j == i) continue;
-                if (lessEnd(b, j, a, i)) { ++idxA; if (sameBinContigStrand(a, b) && mEnd(a) == mEnd(b)) first = false; }
-            }
-            aux[4 * i] = first ? AUX_FIRST_END : 0; aux[4 * i + 1] = idxA;
-        }
+        // ---- child mappers: one (read, bin) segment at a time, bins in ascending order
+        for (u32 i = lane; i < n; i += 64) idxA[i] = i;
         waveFence();
-        // ---- pass B: stale tail of pass 1; child BEGIN pass over the survivors
-        for (u32 i = lane; i < n; i += 64)
+        waveSort(idxA, n, lane, [&](u32 a, u32 b) { return lessEnd(E[a], a, E[b], b); });
+        u32 nM = 0;
+        u32 winErr = 256, winRank = 0;                 // copyCigars: last processed bin among those with the minimal errors
+        u32 p0 = 0;
+        while (p0 < n)
         {
-            const RawMatch a = E[i];
-            u32 flags = aux[4 * i];
-            u32 n1 = 0, posB = 0; bool firstB = true;
-            for (u32 j = 0; j < n; ++j)
+            const u32 bin = E[idxA[p0]].bin;
+            u32 cntBin = 0;
+            for (u32 p = p0 + lane; p < n; p += 64) cntBin += E[idxA[p]].bin == bin;
+            const u32 p1 = p0 + waveSum32(cntBin);
+            // pass 1 (ContigEnd): unique by (contig, strand, end); stale tail = sorted positions >= n1
+            u32 n1 = 0;
+            for (u32 base = p0; base < p1; base += 64)
             {
-                const RawMatch b = E[j];
-                if (b.bin != a.bin || !(aux[4 * j] & AUX_FIRST_END)) continue;
-                ++n1;
-                if (j != i && (flags & AUX_FIRST_END) && lessBegin(b, j, a, i)) { ++posB; if (sameBinContigStrand(a, b) && a.begin == b.begin) firstB = false; }
-            }
-            if (aux[4 * i + 1] >= n1) flags |= AUX_TAIL1;
-            if ((flags & AUX_FIRST_END) && firstB) flags |= AUX_U2;
-            aux[4 * i + 2] = posB;
-            aux[4 * i + 3] = flags;         // staged: pass C must still see the old flags of others
-        }
-        waveFence();
-        for (u32 i = lane; i < n; i += 64) aux[4 * i] = aux[4 * i + 3];
-        waveFence();
-        // ---- pass C: stale tail of pass 2; child primary = rnd-th co-optimal match in coordinate order
-        for (u32 i = lane; i < n; i += 64)
-        {
-            const RawMatch a = E[i];
-            u32 flags = aux[4 * i];
-            u32 n2 = 0, minErr = 255;
-            for (u32 j = 0; j < n; ++j)
-            {
-                const RawMatch b = E[j];
-                if (b.bin != a.bin || !(aux[4 * j] & AUX_U2)) continue;
-                ++n2; if (b.errors < minErr) minErr = b.errors;
-            }
-            if ((flags & AUX_FIRST_END) && aux[4 * i + 2] >= n2) flags |= AUX_TAIL2;
-            if ((flags & AUX_U2) && a.errors == minErr)
-            {
-                u32 nOpt = 0, ord = 0;
-                for (u32 j = 0; j < n; ++j)
+                const u32 p = base + lane;
+                bool first = false;
+                if (p < p1)
                 {
-                    const RawMatch b = E[j];
-                    if (b.bin != a.bin || !(aux[4 * j] & AUX_U2) || b.errors != minErr) continue;
-                    ++nOpt; if (j != i && lessBegin(b, j, a, i)) ++ord;
+                    const RawMatch a = E[idxA[p]];
+                    first = p == p0;
+                    if (!first) { const RawMatch b = E[idxA[p - 1]]; first = !(sameBinContigStrand(a, b) && mEnd(a) == mEnd(b)); }
                 }
-                if (ord == libcxxFirstUniform(nOpt)) flags |= AUX_PRIMARY;
+                const u32 slot = wavePush(first, lane, n1);
+                if (first) idxB[slot] = idxA[p];
             }
-            aux[4 * i + 3] = flags;
-        }
-        waveFence();
-        for (u32 i = lane; i < n; i += 64) aux[4 * i] = aux[4 * i + 3];
-        if (lane == 0) mCount = 0;
-        waveFence();
-        // ---- pass D: copyCigars winner = last processed bin whose child primary has the minimal error count;
-        //      alignMatches for gapped child primaries (shrinks the match); build the main mapper's match array
-        u32 myMin = 255;
-        for (u32 i = lane; i < n; i += 64) if (aux[4 * i] & AUX_PRIMARY) myMin = min(myMin, (u32)E[i].errors);
-        const u32 globalMin = waveMin32(myMin);
-        u32 myBestRank = 0;
-        for (u32 i = lane; i < n; i += 64)
-            if ((aux[4 * i] & AUX_PRIMARY) && E[i].errors == globalMin) myBestRank = max(myBestRank, A.binOrderRank[E[i].bin] + 1);
-        const u32 winnerRank = waveMax32(myBestRank);     // > 0
-        for (u32 base = 0; base < n; base += 64)
-        {
-            const u32 i = base + lane;
-            RawMatch a; u32 flags = 0;
-            if (i < n) { a = E[i]; flags = aux[4 * i]; }
-            const bool isPrim = flags & AUX_PRIMARY;
-            const bool gapped = isPrim && !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
-            const bool winner = isPrim && a.errors == globalMin && A.binOrderRank[a.bin] + 1 == winnerRank;
-            if (winner && !gapped)
+            for (u32 base = p0 + n1; base < p1; base += 64)
             {
-                A.cigars[ro.cigarBegin] = (readLen << 4) | 0;
-                A.out[read].cigarLen = 1;                   // rest of the record is written by lane 0 at the end
+                const u32 p = base + lane;
+                const u32 slot = wavePush(p < p1, lane, nM);
+                if (p < p1) M[slot] = E[idxA[p]];
             }
-            u64 todo = __ballot(gapped);
-            while (todo)
+            waveFence();
+            // pass 2 (ContigBegin) over the n1 survivors
+            waveSort(idxB, n1, lane, [&](u32 a, u32 b) { return lessBegin(E[a], a, E[b], b); });
+            u32 n2 = 0, myMin = 255;
+            for (u32 base = 0; base < n1; base += 64)
             {
-                const u32 l = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                if (lane == l)
+                const u32 q = base + lane;
+                bool first = false;
+                if (q < n1)
                 {
-                    const BinDesc & bd = A.bins[a.bin];
-                    const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
-                    int cb, ce;
-                    u32 nc = alignMatchDevice(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors, dp,
-                                              winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
-                    if (winner) A.out[read].cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
-                    a.begin += (u32)cb; a.len = (u16)ce;   // sic: endPosition(contigGaps), reference src/mapper_aligner.h:213-218
+                    const RawMatch a = E[idxB[q]];
+                    first = q == 0;
+                    if (!first) { const RawMatch b = E[idxB[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
+                    if (first) myMin = min(myMin, (u32)a.errors);
                 }
+                const u64 bal = __ballot(first);
+                n2 += (u32)__popcll(bal);
             }
-            if (i < n)
+            const u32 minErr = waveMin32(myMin);
+            for (u32 base = n2; base < n1; base += 64)
+            {   // stale tail of pass 2
+                const u32 q = base + lane;
+                const u32 slot = wavePush(q < n1, lane, nM);
+                if (q < n1) M[slot] = E[idxB[q]];
+            }
+            // rankMatches (child): primary = rnd-th co-optimal match in coordinate order among the unique ones
+            u32 nOptB = 0;
+            for (u32 base = 0; base < n1; base += 64)
             {
-                if (flags & AUX_U2) { u32 p = atomicAdd(&mCount, 1u); M[p] = a; }
-                const RawMatch orig = E[i];
-                if (flags & AUX_TAIL2) { u32 p = atomicAdd(&mCount, 1u); M[p] = orig; }
-                if (flags & AUX_TAIL1) { u32 p = atomicAdd(&mCount, 1u); M[p] = orig; }
+                const u32 q = base + lane;
+                bool opt = false;
+                if (q < n1)
+                {
+                    const RawMatch a = E[idxB[q]];
+                    bool first = q == 0;
+                    if (!first) { const RawMatch b = E[idxB[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
+                    opt = first && a.errors == minErr;
+                }
+                nOptB += (u32)__popcll(__ballot(opt));
             }
+            const u32 pickB = libcxxFirstUniform(nOptB);
+            u32 optSeen = 0;
+            const u32 binRank = A.binOrderRank[bin] + 1;
+            for (u32 base = 0; base < n1; base += 64)
+            {
+                const u32 q = base + lane;
+                RawMatch a; bool first = false;
+                if (q < n1)
+                {
+                    a = E[idxB[q]];
+                    first = q == 0;
+                    if (!first) { const RawMatch b = E[idxB[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
+                }
+                const bool opt = first && a.errors == minErr;
+                const u64 balOpt = __ballot(opt);
+                const u32 myOptRank = optSeen + (u32)__popcll(balOpt & ((1ull << lane) - 1));
+                optSeen += (u32)__popcll(balOpt);
+                const bool isPrim = opt && myOptRank == pickB;
+                const u64 balPrim = __ballot(isPrim);
+                if (balPrim)
+                {
+                    const u32 pl = __ffsll((long long)balPrim) - 1;     // the lane holding this bin's primary
+                    const bool winner = minErr < winErr || (minErr == winErr && binRank > winRank);   // uniform
+                    if (lane == pl)
+                    {
+                        const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
+                        if (gapped)
+                        {   // alignMatches: CIGAR + shrink
+                            const BinDesc & bd = A.bins[a.bin];
+                            const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+                            int cb, ce;
+                            const u32 nc = alignMatchDevice(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors, dp,
+                                                            winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
+                            if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+                            a.begin += (u32)cb; a.len = (u16)ce;      // sic: endPosition(contigGaps), reference src/mapper_aligner.h:213-218
+                        }
+                        else if (winner) { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
+                    }
+                    ro.cigarLen = __shfl(ro.cigarLen, pl, 64);
+                    if (winner) { winErr = minErr; winRank = binRank; }
+                }
+                const u32 slot = wavePush(first, lane, nM);
+                if (first) M[slot] = a;
+            }
+            waveFence();
+            p0 = p1;
         }
+        // ---- main mapper: aggregateMatches + rankMatches2 over the union
+        for (u32 i = lane; i < nM; i += 64) idxM[i] = i;
         waveFence();
-        const u32 nM = mCount;
-        // ---- pass E: main END pass
-        for (u32 i = lane; i < nM; i += 64)
+        waveSort(idxM, nM, lane, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
+        u32 m1 = 0;
+        for (u32 base = 0; base < nM; base += 64)
         {
-            const RawMatch a = M[i];
-            bool first = true;
-            for (u32 j = 0; j < nM && first; ++j)
+            const u32 p = base + lane;
+            bool first = false;
+            if (p < nM)
             {
-                if (j == i) continue;
-                const RawMatch b = M[j];
-                if (sameBinContigStrand(a, b) && mEnd(a) == mEnd(b) && lessEnd(b, j, a, i)) first = false;
+                const RawMatch a = M[idxM[p]];
+                first = p == 0;
+                if (!first) { const RawMatch b = M[idxM[p - 1]]; first = !(sameBinContigStrand(a, b) && mEnd(a) == mEnd(b)); }
             }
-            maux[2 * i] = first ? 1u : 0u;
+            const u32 slot = wavePush(first, lane, m1);
+            if (first) idxF[slot] = idxM[p];
         }
         waveFence();
-        // ---- pass F: main BEGIN pass over the survivors
-        for (u32 i = lane; i < nM; i += 64)
+        waveSort(idxF, m1, lane, [&](u32 a, u32 b) { return lessBegin(M[a], a, M[b], b); });
+        u32 m2 = 0;
+        for (u32 base = 0; base < m1; base += 64)
         {
-            const RawMatch a = M[i];
-            bool keep = maux[2 * i] & 1;
-            for (u32 j = 0; j < nM && keep; ++j)
+            const u32 q = base + lane;
+            bool first = false;
+            if (q < m1)
             {
-                if (j == i || !(maux[2 * j] & 1)) continue;
-                const RawMatch b = M[j];
-                if (sameBinContigStrand(a, b) && a.begin == b.begin && lessBegin(b, j, a, i)) keep = false;
+                const RawMatch a = M[idxF[q]];
+                first = q == 0;
+                if (!first) { const RawMatch b = M[idxF[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
             }
-            maux[2 * i + 1] = keep ? 1u : 0u;
+            const u32 slot = wavePush(first, lane, m2);
+            if (first) idxM[slot] = idxF[q];
         }
         waveFence();
-        // ---- pass G: rankMatches2 — sort by errors (stable over coordinate order), strata clip, primary pick
-        u32 myMinE = 255;
-        for (u32 i = lane; i < nM; i += 64) if (maux[2 * i + 1]) myMinE = min(myMinE, (u32)M[i].errors);
-        const u32 minE = waveMin32(myMinE);
+        waveSort(idxM, m2, lane, [&](u32 a, u32 b) { return lessErrors(M[a], a, M[b], b); });
+        const u32 minE = M[idxM[0]].errors;
         const u32 strata = readStrataOf(readLen, A.strataRate);
-        u32 myOpt = 0, mySet = 0;
-        for (u32 i = lane; i < nM; i += 64)
-            if (maux[2 * i + 1]) { myOpt += M[i].errors == minE; mySet += M[i].errors <= minE + strata; }
-        const u32 nOpt = waveSum32(myOpt), nSet = waveSum32(mySet);
+        u32 cOpt = 0, cSet = 0;
+        for (u32 q = lane; q < m2; q += 64) { const u32 e = M[idxM[q]].errors; cOpt += e == minE; cSet += e <= minE + strata; }
+        const u32 nOpt = waveSum32(cOpt), nSet = waveSum32(cSet);
         const u32 pick = libcxxFirstUniform(nOpt);
-        for (u32 i = lane; i < nM; i += 64)
+        for (u32 q = lane; q < nSet; q += 64)
         {
-            if (!maux[2 * i + 1]) continue;
-            const RawMatch a = M[i];
-            if (a.errors > minE + strata) continue;
-            u32 rank = 0;
-            for (u32 j = 0; j < nM; ++j)
-            {
-                if (j == i || !maux[2 * j + 1]) continue;
-                if (lessErrors(M[j], j, a, i)) ++rank;
-            }
+            const RawMatch a = M[idxM[q]];
             OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
-            A.outSet[(size_t)ro.setBegin + rank] = om;
-            if (rank == pick)
-            {
-                ReadOut * o = &A.out[read];
-                o->contig = om.contig; o->begin = om.begin; o->length = om.length; o->errors = om.errors; o->isRev = om.isRev;
-                o->mapped = a.len != 0;
-            }
+            A.outSet[(size_t)ro.setBegin + q] = om;
         }
         if (lane == 0)
         {
-            ReadOut * o = &A.out[read];
-            o->bestCount = nOpt; o->subCount = nSet - nOpt;
+            const RawMatch a = M[idxM[pick]];
+            ro.contig = A.bins[a.bin].contigIdBase + a.contig; ro.begin = a.begin; ro.length = a.len; ro.errors = a.errors; ro.isRev = a.strand;
+            ro.mapped = a.len != 0; ro.bestCount = nOpt; ro.subCount = nSet - nOpt;
+            A.out[read] = ro;
         }
         waveFence();
     }

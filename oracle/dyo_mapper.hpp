@@ -105,17 +105,22 @@ struct Match
     bool valid() const { return contigLen != 0; }
 };
 
-// reference src/bits_matches.h:504-528 (ContigSize bits = 32 here; only the lexicographic order matters)
+// reference src/bits_matches.h:504-528 (ContigSize bits = 32 here; only the lexicographic order matters).
+// The reference sorts with std::sort on (contig, strand, end|begin, errors) and so leaves matches with equal keys in an
+// unspecified order; the restatement fixes that order with the remaining coordinate as a last key (a TOTAL order), which
+// is what the device path uses too.  The gold SAMs are reproduced either way.
 struct KeyEnd   { bool operator()(const Match & a, const Match & b) const {
     if (a.contigId != b.contigId) return a.contigId < b.contigId;
     if (a.isRev != b.isRev) return a.isRev < b.isRev;
     if (a.contigEnd() != b.contigEnd()) return a.contigEnd() < b.contigEnd();
-    return a.errors < b.errors; } };
+    if (a.errors != b.errors) return a.errors < b.errors;
+    return a.contigBegin < b.contigBegin; } };
 struct KeyBegin { bool operator()(const Match & a, const Match & b) const {
     if (a.contigId != b.contigId) return a.contigId < b.contigId;
     if (a.isRev != b.isRev) return a.isRev < b.isRev;
     if (a.contigBegin != b.contigBegin) return a.contigBegin < b.contigBegin;
-    return a.errors < b.errors; } };
+    if (a.errors != b.errors) return a.errors < b.errors;
+    return a.contigEnd() < b.contigEnd(); } };
 inline bool dupEnd(const Match & a, const Match & b)   { return a.contigId == b.contigId && a.isRev == b.isRev && a.contigEnd() == b.contigEnd(); }
 inline bool dupBegin(const Match & a, const Match & b) { return a.contigId == b.contigId && a.isRev == b.isRev && a.contigBegin == b.contigBegin; }
 

@@ -1,0 +1,154 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. C API over the CPU restatement so that tests/ (ctypes) can compare the device
+// path with it on the same inputs.  Record layouts deliberately mirror include/dyhip.h (dy_match, dy_read_result).
+#include "dyo_dream.hpp"
+
+using namespace dyo;
+
+namespace {
+struct OMatch { u32 contig; u32 begin; u16 length; u8 errors; u8 is_rev; };
+struct ORead { OMatch primary; u32 mapped, best_count, sub_count, mapq, set_begin, cigar_begin, cigar_len; };
+struct OResult { std::vector<ORead> reads; std::vector<OMatch> matches; std::vector<u32> cigars; DreamStats stats; };
+thread_local std::string g_err;
+OMatch conv(const Match & m) { OMatch o; o.contig = m.contigId; o.begin = (u32)m.contigBegin; o.length = (u16)m.contigLen; o.errors = (u8)m.errors; o.is_rev = m.isRev; return o; }
+ReadBatch makeBatch(const u8 * seqs, const u64 * offs, u32 n)
+{
+    ReadBatch b;
+    for (u32 i = 0; i < n; ++i)
+    {
+        size_t len = (size_t)(offs[i + 1] - offs[i]);
+        std::vector<u8> f(seqs + offs[i], seqs + offs[i] + len), r(len);
+        for (size_t k = 0; k < len; ++k) { u8 c = f[len - 1 - k]; r[k] = c < 4 ? (u8)(3 - c) : (u8)4; }
+        b.names.push_back(std::to_string(i)); b.fwd.push_back(f); b.rev.push_back(r); b.qual.emplace_back(len, 'I');
+    }
+    return b;
+}
+}
+
+extern "C" {
+
+const char * dyo_last_error() { return g_err.c_str(); }
+
+void * dyo_ibf_load(const char * path)
+{
+    try { IBF * f = new IBF; f->load(path); return f; } catch (std::exception const & e) { g_err = e.what(); return nullptr; }
+}
+void dyo_ibf_free(void * f) { delete (IBF *)f; }
+void dyo_ibf_info(void * f, u64 * out) { IBF * i = (IBF *)f; out[0] = i->noOfBits; out[1] = i->noOfBins; out[2] = i->noOfHashFunc; out[3] = i->kmerSize; out[4] = i->binIntWidth; out[5] = i->noOfHashPos; }
+
+// whichBins(fwd) | whichBins(revcomp) per read, W words each
+int dyo_ibf_query(void * fv, const u8 * seqs, const u64 * offs, u32 n, u16 threshold, u64 * masks)
+{
+    try
+    {
+        IBF & f = *(IBF *)fv;
+        for (u32 i = 0; i < n; ++i)
+        {
+            size_t len = (size_t)(offs[i + 1] - offs[i]);
+            std::vector<u8> rc(len);
+            for (size_t k = 0; k < len; ++k) { u8 c = seqs[offs[i] + len - 1 - k]; rc[k] = c < 4 ? (u8)(3 - c) : (u8)4; }
+            std::vector<bool> sel(f.noOfBins, false);
+            if (len >= f.kmerSize)
+            {
+                ibfWhichBins(f, sel, seqs + offs[i], len, threshold);
+                ibfWhichBins(f, sel, rc.data(), len, threshold);
+            }
+            else if (threshold == 0) sel.assign(f.noOfBins, true);
+            for (u32 w = 0; w < f.binIntWidth; ++w) masks[(size_t)i * f.binIntWidth + w] = 0;
+            for (u32 b = 0; b < f.noOfBins; ++b) if (sel[b]) masks[(size_t)i * f.binIntWidth + b / 64] |= 1ull << (b % 64);
+            if (threshold == 0 && len < f.kmerSize)
+                for (u32 w = 0; w < f.binIntWidth; ++w) masks[(size_t)i * f.binIntWidth + w] = ~0ull;
+        }
+        return 0;
+    }
+    catch (std::exception const & e) { g_err = e.what(); return -1; }
+}
+
+// build a filter file: one bin per sequence (codes), for tests
+int dyo_ibf_build(const char * path, u32 bins, u32 hashes, u32 k, u64 bitsWithoutTrailer, const u8 * seqs, const u64 * offs, u32 nSeqs)
+{
+    try
+    {
+        IBF f; f.create(bins, hashes, k, bitsWithoutTrailer + 256);
+        for (u32 i = 0; i < nSeqs && i < bins; ++i)
+        {
+            size_t len = (size_t)(offs[i + 1] - offs[i]);
+            if (len >= k) ibfAddKmers(f, seqs + offs[i], len, i);
+        }
+        f.save(path);
+        return 0;
+    }
+    catch (std::exception const & e) { g_err = e.what(); return -1; }
+}
+
+void * dyo_index_load(const char * dir, u32 nBins)
+{
+    try { std::string d(dir); while (d.size() > 1 && d.back() == '/') d.pop_back(); return new DreamIndex(loadDreamIndex(d, nBins)); }
+    catch (std::exception const & e) { g_err = e.what(); return nullptr; }
+}
+void dyo_index_free(void * p) { delete (DreamIndex *)p; }
+
+// index one bin from codes (one contig per sequence) and write its 12 files under prefix
+int dyo_index_build(const char * prefix, const u8 * seqs, const u64 * offs, u32 nContigs)
+{
+    try
+    {
+        std::vector<std::string> names; std::vector<std::vector<u8> > cs;
+        for (u32 i = 0; i < nContigs; ++i) { names.push_back("contig" + std::to_string(i)); cs.emplace_back(seqs + offs[i], seqs + offs[i + 1]); }
+        saveBinIndex(buildBinIndex(names, cs), prefix);
+        return 0;
+    }
+    catch (std::exception const & e) { g_err = e.what(); return -1; }
+}
+
+void * dyo_map_batch(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
+                     unsigned hitsThreshold, unsigned threads)
+{
+    try
+    {
+        DreamIndex & idx = *(DreamIndex *)idxv;
+        Options opt; opt.errorRate = errorRate; opt.strataRate = strataRate; opt.sensitivity = sensitivity; opt.hitsThreshold = hitsThreshold;
+        opt.threads = threads; opt.useFilter = ibfv != nullptr;
+        ReadBatch batch = makeBatch(seqs, offs, n);
+        DreamMapper mapper(idx, (IBF *)ibfv, opt);
+        OResult * R = new OResult;
+        std::vector<ReadResult> res = mapper.mapBatch(batch, &R->stats);
+        R->reads.resize(n);
+        for (u32 i = 0; i < n; ++i)
+        {
+            ORead & o = R->reads[i];
+            const ReadResult & r = res[i];
+            memset(&o, 0, sizeof(o));
+            o.mapped = r.mapped; o.best_count = r.mapped ? r.bestCount : 0; o.sub_count = r.mapped ? r.subCount : 0;
+            o.primary.errors = 127;
+            o.set_begin = (u32)R->matches.size(); o.cigar_begin = (u32)R->cigars.size();
+            if (r.mapped)
+            {
+                o.primary = conv(r.primary);
+                double rate = (double)((float)r.primary.errors / (float)batch.fwd[i].size());
+                o.mapq = getMapq(getMatchProb(rate, rate, r.bestCount, r.subCount));
+                for (auto & m : r.matches) R->matches.push_back(conv(m));
+                for (auto & c : r.cigar) R->cigars.push_back((c.count << 4) | (c.op == 'M' ? 0u : c.op == 'I' ? 1u : 2u));
+                o.cigar_len = (u32)r.cigar.size();
+            }
+        }
+        return R;
+    }
+    catch (std::exception const & e) { g_err = e.what(); return nullptr; }
+}
+void dyo_result_free(void * r) { delete (OResult *)r; }
+u64 dyo_result_n_matches(void * r) { return ((OResult *)r)->matches.size(); }
+u64 dyo_result_n_cigars(void * r) { return ((OResult *)r)->cigars.size(); }
+void dyo_result_copy(void * rv, void * reads, void * matches, u32 * cigars)
+{
+    OResult * r = (OResult *)rv;
+    memcpy(reads, r->reads.data(), r->reads.size() * sizeof(ORead));
+    if (!r->matches.empty()) memcpy(matches, r->matches.data(), r->matches.size() * sizeof(OMatch));
+    if (!r->cigars.empty()) memcpy(cigars, r->cigars.data(), r->cigars.size() * 4);
+}
+void dyo_result_stats(void * rv, u64 * out)
+{
+    OResult * r = (OResult *)rv;
+    out[0] = r->stats.filteredReads; out[1] = r->stats.bin.matches; out[2] = r->stats.bin.seeds; out[3] = r->stats.bin.hits; out[4] = r->stats.bin.located;
+}
+
+} // extern "C"
