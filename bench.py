@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — DREAM-Yara mapping hot path on MI355X: mapped reads/s, 100 bp SE, 64-bin IBF (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the whole device path over one resident batch: K1 IBF sweep -> read->bin work list -> K2 seed search
+-> K3 classify/rank/locate/extend -> per-read aggregation (dedupe, strata, primary, CIGAR of primaries).  Inputs (reads,
+filter, indices) are in HBM before the timed region; results stay in HBM (the PCIe-inclusive rate is in DESIGN.md).
+Multi-GPU: reads are sharded across ranks, every rank holds the filter and all bins (1 GiB + ~1.4 GB of 288 GB), so
+there is no data-path collective; scaling is weak (1 M reads per GPU per step).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: bins, genome length per bin, IBF GiB, k, hashes, reads per GPU, read length, error %
+    "config2": dict(bins=64, glen=4_000_000, ibf_gib=1, k=18, h=3, reads=1_000_000, L=100, e=3,
+                    desc="64 bins x 4 Mbp, 1 GiB IBF (k=18, 3 hashes), 1M synthetic 100 bp SE reads, e=3"),
+    # small variant for smoke runs / CI (NOT the reported configuration)
+    "tiny": dict(bins=64, glen=100_000, ibf_gib=0, k=18, h=3, reads=20_000, L=100, e=3,
+                 desc="64 bins x 100 kbp, 32 MiB IBF, 20k reads (smoke only)"),
+}
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def shard_reads(n_total_per_rank, rank):
+    """Weak scaling: every rank simulates its own batch; the seed differs per rank (SURVEY.md §8d seeds + rank)."""
+    return 0x5EED0000 + 2 + 1000 * rank
+
+
+def build_inputs(wl, work_dir, rank, world, barrier):
+    """Setup (untimed): genomes, index files (rank 0 builds, all load), reads. Returns (genomes, index_dir)."""
+    from dream_yara_amd import synth
+    t0 = time.time()
+    genomes = [synth.make_genome(b, wl["glen"]) for b in range(wl["bins"])]
+    idx_dir = os.path.join(work_dir, "index")
+    done_flag = os.path.join(idx_dir, "DONE")
+    if rank == 0 and not os.path.exists(done_flag):
+        if os.path.exists(idx_dir):
+            shutil.rmtree(idx_dir)
+        os.makedirs(idx_dir)
+        synth.build_index_dir(genomes, idx_dir, threads=min(32, max(1, (os.cpu_count() or 1))))
+        shutil.rmtree(os.path.join(idx_dir, "fasta"), ignore_errors=True)
+        open(done_flag, "w").write("ok\n")
+    barrier()
+    log("rank %d: genomes + index ready in %.1f s" % (rank, time.time() - t0))
+    return genomes, idx_dir + "/"
+
+
+def cpu_baseline(wl, idx_dir, filter_path, codes, offs, error_rate, sample_reads):
+    """Oracle (CPU restatement of the reference path, kind 'port') on a bounded sample of the same workload."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    n = min(sample_reads, offs.size - 1)
+    sub_codes = codes[: int(offs[n])]
+    sub_offs = offs[: n + 1]
+    oibf = ob.OracleIbf(filter_path)
+    oidx = ob.OracleIndex(idx_dir, wl["bins"])
+    t0 = time.time()
+    reads, _, _, _ = ob.map_batch(oidx, oibf, sub_codes, sub_offs, error_rate, threads=threads)
+    dt = time.time() - t0
+    oidx.close(); oibf.close()
+    return {"value": n / dt, "unit": "reads/s", "cores": threads, "kind": "port",
+            "sample": "%d reads of the same batch, oracle (oracle/dyo_*.hpp) with %d threads, %.1f s; filter/index load excluded" % (n, threads, dt),
+            "mapped_fraction": float(reads["mapped"].mean())}, reads
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=60000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import dream_yara_amd as dy
+    from dream_yara_amd import synth, build as dybuild
+    if not os.path.exists(dy.LIB_PATH):
+        dybuild.build()
+    if dy.device_count() == 0:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+
+    work_dir = os.path.join(args.work_dir, args.workload)
+    os.makedirs(work_dir, exist_ok=True)
+    genomes, idx_dir = build_inputs(wl, work_dir, rank, world, barrier)
+
+    ctx = dy.Context(local_rank)
+    t0 = time.time()
+    n_bits = (wl["ibf_gib"] << 33) if wl["ibf_gib"] else (1 << 28)
+    ibf = dy.Ibf.create(ctx, wl["bins"], wl["h"], wl["k"], n_bits + 256)
+    for b, g in enumerate(genomes):
+        ibf.add(g, b)
+    index = dy.Index(ctx, idx_dir, wl["bins"])
+    log("rank %d: filter built on device + index uploaded in %.1f s" % (rank, time.time() - t0))
+
+    t0 = time.time()
+    codes, offs, truth = synth.simulate_reads(genomes, wl["reads"], wl["L"], seed=shard_reads(wl["reads"], rank))
+    reads = dy.Reads(ctx, codes, offs)
+    del genomes
+    log("rank %d: %d reads simulated + uploaded in %.1f s" % (rank, wl["reads"], time.time() - t0))
+
+    error_rate = np.float32(wl["e"] / 100.0)
+    params = dy.default_params(error_rate=error_rate)
+    thr = dy.threshold(error_rate, wl["k"], wl["L"])
+
+    def step():
+        ibf.query(reads, thr, want_masks=False)
+        res = dy.map_reads(ctx, index, reads, params, asynchronous=True)
+        ctx.sync()
+        return res
+
+    last = None
+    for _ in range(args.warmup):
+        r = step()
+        r.close()
+    stage_ms = {k: 0.0 for k in ("ms_ibf", "ms_items", "ms_search", "ms_extend", "ms_finalize")}
+    barrier(); torch.cuda.synchronize() if torch.cuda.is_available() else None; ctx.sync()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        r = step()
+        st = ctx.stats()
+        for k in stage_ms:
+            stage_ms[k] += st[k]
+        if i + 1 < args.steps:
+            r.close()
+        else:
+            last = r
+    ctx.sync(); torch.cuda.synchronize() if torch.cuda.is_available() else None; barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness spot-check of the last step against the simulation truth (not timed)
+    rr = last.fetch().reads()
+    stats = ctx.stats()
+    mapped_fraction = float(rr["mapped"].mean())
+    ok_bin = float((rr["primary"]["contig"][rr["mapped"] == 1] == truth["bin"][rr["mapped"] == 1]).mean())
+    last.close()
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = 1e3 * elapsed / steps
+        total_reads = wl["reads"] * world * steps
+        value = total_reads / elapsed
+        # roofline of the dominant HBM kernel K1: algorithmic bytes = strands * (L-k+1) * h * W * 8 B per read
+        W = (wl["bins"] + 63) // 64
+        bytes_per_read = 2 * (wl["L"] - wl["k"] + 1) * wl["h"] * W * 8
+        k1_s = stage_ms["ms_ibf"] / steps / 1e3
+        achieved = bytes_per_read * wl["reads"] / k1_s / 1e9 if k1_s > 0 else 0.0
+        out = {
+            "metric": "mapped reads/sec (whole node), 100 bp SE, 64-bin IBF",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": wl["desc"], "reads_per_gpu_per_step": wl["reads"], "parallelism": "reads sharded x%d, filter+index replicated" % world,
+                       "mapped_fraction": mapped_fraction, "primary_in_true_bin": ok_bin,
+                       "items_per_read": stats["items"] / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
+                       "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
+            "roofline": {"kernel": "k_ibf_query", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "note": "algorithmic bytes %d B/read x %d reads per launch; each 8 B word costs a 64 B HBM fetch at W=1 (hardware bytes = 8x)" % (bytes_per_read, wl["reads"])},
+        }
+        if args.cpu_sample > 0 and world == 1:
+            fpath = os.path.join(work_dir, "bench.filter")
+            ibf.save(fpath)
+            base, oreads = cpu_baseline(wl, idx_dir, fpath, codes, offs, error_rate, args.cpu_sample)
+            # the sample doubles as a parity check of the timed configuration
+            n = oreads.size
+            same = (np.array_equal(oreads["mapped"], rr["mapped"][:n]) and
+                    np.array_equal(oreads["primary"]["begin"][oreads["mapped"] == 1], rr["primary"]["begin"][:n][oreads["mapped"] == 1]) and
+                    np.array_equal(oreads["best_count"], rr["best_count"][:n]) and np.array_equal(oreads["mapq"], rr["mapq"][:n]))
+            base["parity_with_gpu_on_sample"] = bool(same)
+            out["cpu_baseline"] = base
+            try:
+                os.remove(fpath)
+            except OSError:
+                pass
+        print(json.dumps(out), flush=True)
+    barrier()
+    reads.close(); index.close(); ibf.close(); ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

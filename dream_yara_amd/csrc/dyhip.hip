@@ -76,7 +76,7 @@ struct dy_ctx
     dy_map_stats stats = {};
     bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
-    DevBuf waveCounts, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
+    DevBuf waveCounts, waveOffsets, complexList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp;
     size_t poolCap = 0;
 };
@@ -435,20 +435,28 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         // ---- work list (bin-major)
         HIP_CHECK(hipEventRecord(ctx->ev[2], st));
         const u32 nWaves = (nReads + 63) / 64;
-        ctx->waveCounts.reserve((size_t)nBins * nWaves * 4);
-        ctx->binTotals.reserve((size_t)nBins * 4); ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
+        const size_t nCells = (size_t)nBins * nWaves;
+        ctx->waveCounts.reserve((nCells + 1) * 4); ctx->waveOffsets.reserve((nCells + 1) * 4);
+        ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
+        HIP_CHECK(hipMemsetAsync(ctx->waveCounts.as<u32>() + nCells, 0, 4, st));
         hipLaunchKernelGGL(k_items_count, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins, ctx->waveCounts.as<u32>());
-        hipLaunchKernelGGL(k_items_scan_bins, dim3((nBins + 63) / 64), dim3(64), 0, st, ctx->waveCounts.as<u32>(), nWaves, nBins, ctx->binTotals.as<u32>());
-        hipLaunchKernelGGL(k_items_bin_starts, dim3(1), dim3(64), 0, st, ctx->binTotals.as<u32>(), nBins, ctx->binStart.as<u32>(), ctx->binOrderRank.as<u32>());
+        {
+            size_t tmpBytes = 0;
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
+            ctx->scanTmp.reserve(tmpBytes + 64);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
+        }
+        hipLaunchKernelGGL(k_items_bin_starts, dim3((nBins + 1 + 63) / 64), dim3(64), 0, st, ctx->waveOffsets.as<u32>(), ctx->waveOffsets.as<u32>() + nCells,
+                           nWaves, nBins, ctx->binStart.as<u32>(), ctx->binOrderRank.as<u32>());
         u32 nItems = 0;
-        HIP_CHECK(hipMemcpyAsync(&nItems, ctx->binStart.as<u32>() + nBins, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (ctx->ibfTimingPending) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; ctx->ibfTimingPending = false; }
         ctx->stats.items = nItems;
         ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
         if (nItems)
             hipLaunchKernelGGL(k_items_scatter, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins,
-                               ctx->waveCounts.as<u32>(), ctx->binStart.as<u32>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>());
+                               ctx->waveOffsets.as<u32>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>());
         HIP_CHECK(hipEventRecord(ctx->ev[3], st));
 
         // ---- K2: exact search of the round-0 seeds
@@ -521,6 +529,11 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate;
         fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
         fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
+        fa.debugFlags = getenv("DY_DEBUG_FINALIZE") ? (u32)atoi(getenv("DY_DEBUG_FINALIZE")) : 0;
+        ctx->complexList.reserve((size_t)nReads * 4 + 64);
+        u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
+        fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
+        hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount);
         hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));

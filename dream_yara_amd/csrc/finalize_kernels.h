@@ -43,6 +43,9 @@ struct FinalizeArgs
     ReadOut * out;
     OutMatch * outSet;            // 3 per raw match (only the first nSet of a read's region are meaningful)
     u32 * cigars; u32 cigarStride;
+    // reads that need the full aggregation (more than one raw match, or a gapped single match); the others were written by k_finalize_simple
+    const u32 * complexList; const u32 * complexCount;
+    u32 debugFlags;               // DY_DEBUG_FINALIZE (timing experiments only): 1 = skip the alignment DP, 2 = skip child passes
 };
 
 // libc++ std::default_random_engine (minstd_rand, seed 1) + uniform_int_distribution<size_t>(0, n-1), first draw
@@ -249,10 +252,220 @@ __device__ inline u32 alignMatchDevice(const u8 * __restrict__ ctg, int n, const
     return nc;
 }
 
+// Single-thread form for short reads and narrow bands (readLen <= 160, e <= 7): the three band rows live in registers
+// (loops fully unrolled over the 15 possible diagonals), the trace is one 64-bit word per row (4 bits per cell) in
+// private memory.  Same values, tie-breaks and traceback as alignMatchDevice; used by the one-match fast path.
+enum { THREAD_DP_MAX_LEN = 160, THREAD_DP_MAX_E = 7 };
+__device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const u8 * __restrict__ seq, u32 readLen, u32 strand, int e,
+                                       u32 * cigarOut, u32 cigarCap, int & clipBegin, int & clipEnd)
+{
+    enum { BM = 2 * THREAD_DP_MAX_E + 1 };
+    const int m = (int)readLen, B = 2 * e + 1;
+    const int NEG = -(1 << 28), MISMATCH = -1000, GEXT = -999, GOPEN = -1001;
+    u64 trace[THREAD_DP_MAX_LEN + 1];
+    int pS[BM], pV[BM];
+#pragma unroll
+    for (int d = 0; d < BM; ++d) { const int j = d - e; pS[d] = (d < B && j >= 0 && j <= n) ? 0 : NEG; pV[d] = NEG; }
+    trace[0] = 0;
+    for (int i = 1; i <= m; ++i)
+    {
+        const u32 rc = readBase(seq, readLen, strand, (u32)(i - 1));
+        int cS[BM], cV[BM];
+        int leftS = NEG, leftH = NEG;
+        u64 row = 0;
+#pragma unroll
+        for (int d = 0; d < BM; ++d)
+        {
+            const int j = i + d - e;
+            int s = NEG, h = NEG, v = NEG; u32 tr = 0;
+            if (d < B && j >= 0 && j <= n)
+            {
+                if (d + 1 < B)
+                {
+                    const int ext = pV[d + 1 < BM ? d + 1 : d] + GEXT, opn = pS[d + 1 < BM ? d + 1 : d] + GOPEN;
+                    if (ext >= opn) { v = ext; tr |= 4; } else v = opn;
+                }
+                if (d >= 1 && j >= 1)
+                {
+                    const int ext = leftH + GEXT, opn = leftS + GOPEN;
+                    if (ext >= opn) { h = ext; tr |= 8; } else h = opn;
+                }
+                u32 tb = 0;
+                if (j >= 1)
+                {
+                    const u32 cc = ctg[j - 1];
+                    s = pS[d] + ((cc == rc && cc < 4) ? 0 : MISMATCH); tb = 1;
+                }
+                if (v > s) { s = v; tb = 3; }
+                if (h > s) { s = h; tb = 2; }
+                tr |= tb;
+            }
+            cS[d] = s; cV[d] = v; leftS = s; leftH = h;
+            row |= (u64)tr << (4 * d);
+        }
+        trace[i] = row;
+#pragma unroll
+        for (int d = 0; d < BM; ++d) { pS[d] = cS[d]; pV[d] = cV[d]; }
+    }
+    int bj = -1, bs = NEG;
+#pragma unroll
+    for (int d = 0; d < BM; ++d)
+    {
+        const int j = m + d - e;
+        if (d < B && j >= 0 && j <= n && pS[d] > bs) { bs = pS[d]; bj = j; }
+    }
+    // traceback; cigar runs are produced back to front, so count first and fill from the end
+    int i = m, j = bj, state = 0;
+    u32 runs = 0; int lastOp = -1;
+    {
+        int ti = i, tj = j, ts = 0;
+        while (ti > 0)
+        {
+            const u32 tr = (u32)(trace[ti] >> (4 * (tj - ti + e))) & 15;
+            int op;
+            if (ts == 0)
+            {
+                const u32 tb = tr & 3;
+                if (tb == 1) { op = 0; --ti; --tj; }
+                else if (tb == 3) { ts = 1; continue; }
+                else if (tb == 2) { ts = 2; continue; }
+                else break;
+            }
+            else if (ts == 1) { op = 1; --ti; if (!(tr & 4)) ts = 0; }
+            else { op = 2; --tj; if (!(tr & 8)) ts = 0; }
+            if (op != lastOp) { ++runs; lastOp = op; }
+        }
+        clipBegin = tj;
+    }
+    clipEnd = bj;
+    if (cigarOut)
+    {
+        u32 slot = runs; lastOp = -1; u32 run = 0;
+        while (i > 0)
+        {
+            const u32 tr = (u32)(trace[i] >> (4 * (j - i + e))) & 15;
+            int op;
+            if (state == 0)
+            {
+                const u32 tb = tr & 3;
+                if (tb == 1) { op = 0; --i; --j; }
+                else if (tb == 3) { state = 1; continue; }
+                else if (tb == 2) { state = 2; continue; }
+                else break;
+            }
+            else if (state == 1) { op = 1; --i; if (!(tr & 4)) state = 0; }
+            else { op = 2; --j; if (!(tr & 8)) state = 0; }
+            if (op != lastOp)
+            {
+                if (lastOp >= 0) { --slot; if (slot < cigarCap) cigarOut[slot] = (run << 4) | (u32)lastOp; }
+                lastOp = op; run = 0;
+            }
+            ++run;
+        }
+        if (lastOp >= 0) { --slot; if (slot < cigarCap) cigarOut[slot] = (run << 4) | (u32)lastOp; }
+    }
+    return runs;
+}
+
+// Wave-parallel form of alignMatchDevice for bands of at most 64 diagonals: lane d owns diagonal d of the band, a row
+// costs one coalesced contig load, two lane shifts and one max-plus prefix scan (the horizontal gap matrix obeys
+// H[d] = max_{d'<d} (T[d'] + open + ext*(d-d'-1)) with T = max(diagonal, vertical), because open < ext).
+// Values, tie-breaks and the traceback are identical to the sequential form.  All lanes must call it with the same arguments.
+__device__ inline u32 alignMatchWave(const u8 * __restrict__ ctg, int n, const u8 * __restrict__ seq, u32 readLen, u32 strand, int e,
+                                     u8 * scratch, u32 * cigarOut, u32 cigarCap, int & clipBegin, int & clipEnd, u32 lane)
+{
+    const int m = (int)readLen, B = 2 * e + 1, d = (int)lane;
+    const int NEG = -(1 << 28), MISMATCH = -1000, GEXT = -999, GOPEN = -1001;
+    u8 * trace = scratch;
+    u8 * ops = scratch + (size_t)(m + 1) * B;
+    u8 * sRead = ops + m + n + 2;            // strand-resolved read and the contig infix, staged once (coalesced)
+    u8 * sCtg = sRead + m;
+    for (int x = (int)lane; x < m; x += 64) sRead[x] = (u8)readBase(seq, readLen, strand, (u32)x);
+    for (int x = (int)lane; x < n; x += 64) sCtg[x] = ctg[x];
+    const bool inBand = d < B;
+    int pS, pV = NEG;
+    { const int j = d - e; pS = (inBand && j >= 0 && j <= n) ? 0 : NEG; if (inBand) trace[d] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 1; i <= m; ++i)
+    {
+        const u32 rc = sRead[i - 1];
+        const int j = i + d - e;
+        const bool valid = inBand && j >= 0 && j <= n;
+        // vertical: from (i-1, j) = lane d+1 of the previous row
+        const int upS = __shfl_down(pS, 1, 64), upV = __shfl_down(pV, 1, 64);
+        int v = NEG; u8 tr = 0;
+        if (valid && d + 1 < B)
+        {
+            const int ext = upV + GEXT, opn = upS + GOPEN;
+            if (ext >= opn) { v = ext; tr |= 4; } else v = opn;
+        }
+        int t = NEG; u8 tb = 0;
+        if (valid && j >= 1)
+        {
+            const u32 cc = sCtg[j - 1];
+            t = pS + ((cc == rc && cc < 4) ? 0 : MISMATCH); tb = 1;
+        }
+        if (v > t) { t = v; tb = 3; }
+        // horizontal: exclusive prefix max of U = T + 999*d over the lower diagonals of this row
+        const int u = valid ? t - GEXT * d : NEG;
+        int scan = __shfl_up(u, 1, 64); if (lane == 0) scan = NEG;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int other = __shfl_up(scan, o, 64); if ((int)lane >= o && other > scan) scan = other; }
+        int h = NEG;
+        if (valid && d >= 1 && j >= 1) h = scan + GOPEN + GEXT * (d - 1);
+        int sCell = t;
+        if (h > sCell) { sCell = h; tb = 2; }
+        if (!valid) { sCell = NEG; h = NEG; v = NEG; tb = 0; tr = 0; }
+        // extend-vs-open flag of the horizontal move needs the finished left neighbour
+        const int leftS = __shfl_up(sCell, 1, 64), leftH = __shfl_up(h, 1, 64);
+        if (valid && d >= 1 && j >= 1 && leftH + GEXT >= leftS + GOPEN) tr |= 8;
+        if (inBand) trace[(size_t)i * B + d] = (u8)(tr | tb);
+        pS = sCell; pV = v;
+    }
+    // best cell of the last row, leftmost on ties
+    const bool lastValid = inBand && m + d - e >= 0 && m + d - e <= n;
+    const int myBest = lastValid ? pS : NEG;
+    int mx = myBest;
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(mx, o, 64); mx = other > mx ? other : mx; }
+    const u64 atMax = __ballot(lastValid && myBest == mx);
+    const int bd = __ffsll((long long)atMax) - 1;
+    const int bj = m + bd - e;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int i = m, j = bj, state = 0, nops = 0;
+    while (i > 0)
+    {
+        const u8 tr = trace[(size_t)i * B + (j - i + e)];
+        if (state == 0)
+        {
+            const u8 tb = tr & 3;
+            if (tb == 1) { if (lane == 0) ops[nops] = 0; ++nops; --i; --j; }
+            else if (tb == 3) state = 1;
+            else if (tb == 2) state = 2;
+            else break;
+        }
+        else if (state == 1) { if (lane == 0) ops[nops] = 1; ++nops; const bool ext = tr & 4; --i; if (!ext) state = 0; }
+        else { if (lane == 0) ops[nops] = 2; ++nops; const bool ext = tr & 8; --j; if (!ext) state = 0; }
+    }
+    clipBegin = j; clipEnd = bj;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    u32 nc = 0;
+    for (int k = nops - 1; k >= 0; )
+    {
+        const u8 op = ops[k]; u32 run = 0;
+        while (k >= 0 && ops[k] == op) { ++run; --k; }
+        if (cigarOut && nc < cigarCap && lane == 0) cigarOut[nc] = (run << 4) | op;
+        ++nc;
+    }
+    return nc;
+}
+
 __host__ __device__ inline size_t dpScratchBytes(u32 maxReadLen, u32 maxErrors)
 {
     size_t B = 2 * (size_t)maxErrors + 1;
-    return (((size_t)(maxReadLen + 1) * B + 3) & ~(size_t)3) + 6 * B * sizeof(int) + 2 * (size_t)maxReadLen + 2 * maxErrors + 16;
+    return (((size_t)(maxReadLen + 1) * B + 3) & ~(size_t)3) + 6 * B * sizeof(int) + 4 * (size_t)maxReadLen + 4 * maxErrors + 32;
 }
 
 __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
@@ -260,22 +473,34 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
     const u32 lane = threadIdx.x & 63;
     const u32 gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 nWaves = (gridDim.x * blockDim.x) >> 6;
-    u8 * dp = A.dpScratch + (size_t)gwave * A.dpStride;
+    // alignment scratch: LDS when the banded matrices of this batch fit (they do for short reads), else the global slab
+    enum { DP_LDS_BYTES = 4096, SMALL_N = 32 };
+    __shared__ __attribute__((aligned(16))) u8 sDp[4][DP_LDS_BYTES];
+    u8 * dp = A.dpStride <= DP_LDS_BYTES ? sDp[threadIdx.x >> 6] : A.dpScratch + (size_t)gwave * A.dpStride;
+    // reads with few matches (almost all of them) keep every working array in LDS; the rest use the global scratch
+    __shared__ RawMatch sE[4][SMALL_N];
+    __shared__ RawMatch sM[4][3 * SMALL_N];
+    __shared__ u32 sIdx[4][8 * SMALL_N];
 
-    for (u32 read = gwave; read < A.nReads; read += nWaves)
+    const u32 nList = *A.complexCount;
+    for (u32 li = gwave; li < nList; li += nWaves)
     {
+        const u32 read = A.complexList[li];
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
         const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
         const u8 * seq = A.readSeqs + A.readOffs[read];
         ReadOut ro; ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
         ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
         if (n == 0) { if (lane == 0) A.out[read] = ro; continue; }
-        const RawMatch * E = A.gp + s0;
-        u32 * idxA = A.aux + (size_t)4 * s0;           // n entries: all matches of the read in child END order
-        u32 * idxB = idxA + n;                         // <= n entries: pass-1 survivors of the current bin
-        RawMatch * M = A.marr + (size_t)3 * s0;        // the main mapper's matchesByCoord of this read
-        u32 * idxM = A.maux + (size_t)6 * s0;          // 3n
-        u32 * idxF = idxM + (size_t)3 * n;             // 3n
+        const bool small = n <= SMALL_N;
+        const u32 wv = threadIdx.x >> 6;
+        if (small && lane < n) sE[wv][lane] = A.gp[s0 + lane];
+        const RawMatch * E = small ? sE[wv] : A.gp + s0;
+        u32 * idxA = small ? sIdx[wv] : A.aux + (size_t)4 * s0;                 // n entries: all matches of the read in child END order
+        u32 * idxB = idxA + n;                                                  // <= n entries: pass-1 survivors of the current bin
+        RawMatch * M = small ? sM[wv] : A.marr + (size_t)3 * s0;                // the main mapper's matchesByCoord of this read
+        u32 * idxM = small ? sIdx[wv] + 2 * SMALL_N : A.maux + (size_t)6 * s0;  // 3n
+        u32 * idxF = idxM + (size_t)3 * n;                                      // 3n
 
         // ---- child mappers: one (read, bin) segment at a time, bins in ascending order
         for (u32 i = lane; i < n; i += 64) idxA[i] = i;
@@ -374,22 +599,33 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                 {
                     const u32 pl = __ffsll((long long)balPrim) - 1;     // the lane holding this bin's primary
                     const bool winner = minErr < winErr || (minErr == winErr && binRank > winRank);   // uniform
-                    if (lane == pl)
-                    {
-                        const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
-                        if (gapped)
-                        {   // alignMatches: CIGAR + shrink
-                            const BinDesc & bd = A.bins[a.bin];
-                            const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
-                            int cb, ce;
-                            const u32 nc = alignMatchDevice(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors, dp,
-                                                            winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
-                            if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
-                            a.begin += (u32)cb; a.len = (u16)ce;      // sic: endPosition(contigGaps), reference src/mapper_aligner.h:213-218
+                    // broadcast the primary so that the whole wave can align it
+                    const u32 pBegin = __shfl(a.begin, pl, 64), pLen = __shfl((u32)a.len, pl, 64), pErr = __shfl((u32)a.errors, pl, 64);
+                    const u32 pStrand = __shfl((u32)a.strand, pl, 64), pContig = __shfl((u32)a.contig, pl, 64);
+                    const bool gapped = !(pErr == 0 || (pErr == 1 && pLen == readLen));
+                    if (gapped && !(A.debugFlags & 1))
+                    {   // alignMatches: CIGAR + shrink
+                        const BinDesc & bd = A.bins[bin];
+                        const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + pContig] + pBegin;
+                        int cb = 0, ce = (int)pLen;
+                        u32 nc;
+                        if (2 * pErr + 1 <= 64)
+                            nc = alignMatchWave(ctg, (int)pLen, seq, readLen, pStrand, (int)pErr, dp, winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, lane);
+                        else
+                        {
+                            nc = 0;
+                            if (lane == 0)
+                                nc = alignMatchDevice(ctg, (int)pLen, seq, readLen, pStrand, (int)pErr, dp, winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
+                            nc = __shfl(nc, 0, 64); cb = __shfl(cb, 0, 64); ce = __shfl(ce, 0, 64);
                         }
-                        else if (winner) { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
+                        if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+                        if (lane == pl) { a.begin += (u32)cb; a.len = (u16)ce; }      // sic: endPosition(contigGaps), reference src/mapper_aligner.h:213-218
                     }
-                    ro.cigarLen = __shfl(ro.cigarLen, pl, 64);
+                    else if (winner)
+                    {
+                        if (lane == 0) A.cigars[ro.cigarBegin] = (readLen << 4) | 0;
+                        ro.cigarLen = 1;
+                    }
                     if (winner) { winErr = minErr; winRank = binRank; }
                 }
                 const u32 slot = wavePush(first, lane, nM);
@@ -455,6 +691,46 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
         }
         waveFence();
     }
+}
+
+// Fast path, one thread per read: a read without matches is unmapped; a read whose only match is ungapped needs no
+// sorting, no alignment and has X0 = 1, X1 = 0.  Everything else is queued for k_finalize.
+__global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount)
+{
+    const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
+    if (read >= A.nReads) return;
+    const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+    const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+    ReadOut ro; ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
+    ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
+    if (n == 1)
+    {
+        RawMatch a = A.gp[s0];
+        const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
+        const bool inThread = !gapped || (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E && !(A.debugFlags & 2));
+        if (inThread)
+        {
+            if (gapped)
+            {   // alignMatches of the only match: CIGAR + shrink (reference src/mapper_aligner.h:204-236)
+                const BinDesc & bd = A.bins[a.bin];
+                const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+                int cb, ce;
+                const u32 nc = alignMatchThread(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
+                                                A.cigars + ro.cigarBegin, A.cigarStride, cb, ce);
+                ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+                a.begin += (u32)cb; a.len = (u16)ce;
+            }
+            else { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
+            OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
+            A.outSet[(size_t)ro.setBegin] = om;
+            ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
+            ro.mapped = om.length != 0; ro.bestCount = 1; ro.subCount = 0;
+            A.out[read] = ro;
+            return;
+        }
+    }
+    if (n == 0) { A.out[read] = ro; return; }
+    complexList[atomicAdd(complexCount, 1u)] = read;
 }
 
 // readStart-based regrouping of the raw pool

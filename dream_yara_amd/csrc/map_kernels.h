@@ -43,7 +43,8 @@ __host__ __device__ __forceinline__ u32 readStrataOf(u32 len, float strataRate)
 __host__ __device__ __forceinline__ u32 seedCountOf(u32 readErrors, u32 seedErrors) { return (readErrors + 1 + seedErrors) / (seedErrors + 1); }
 
 // ---------------------------------------------------------------------------------------------------
-// Work list: per wave of 64 reads count the reads selected for every bin, scan per bin, scatter (deterministic order).
+// Work list: per wave of 64 reads count the reads selected for every bin, one device-wide exclusive scan of the
+// bin-major count matrix, scatter (deterministic order).
 // ---------------------------------------------------------------------------------------------------
 __global__ void k_items_count(const u64 * __restrict__ masks, u32 nReads, u32 W, u32 nBins, u32 * __restrict__ waveCounts)
 {
@@ -53,50 +54,42 @@ __global__ void k_items_count(const u64 * __restrict__ masks, u32 nReads, u32 W,
     if (gw >= nWaves) return;
     for (u32 w = 0; w < W; ++w)
     {
-        u64 m = read < nReads ? masks[(size_t)read * W + w] : 0;
-        // lane j of this pass accumulates bin w*64+j: count lanes whose bit j is set
+        const u64 m = read < nReads ? masks[(size_t)read * W + w] : 0;
+        // lane j ends up with the number of reads of this wave selected for bin w*64+j
         u32 cnt = 0;
-        for (u32 src = 0; src < 64; ++src)
+        for (u32 j = 0; j < 64; ++j)
         {
-            u32 lo = __shfl((u32)m, src, 64), hi = __shfl((u32)(m >> 32), src, 64);
-            u64 ms = ((u64)hi << 32) | lo;
-            cnt += (u32)((ms >> lane) & 1);
+            const u32 c = (u32)__popcll(__ballot((m >> j) & 1));
+            if (lane == j) cnt = c;
         }
-        u32 bin = w * 64 + lane;
+        const u32 bin = w * 64 + lane;
         if (bin < nBins) waveCounts[(size_t)bin * nWaves + gw] = cnt;
     }
 }
 
-// one thread per bin: exclusive scan of its row of waveCounts (in place), total into binTotals
-__global__ void k_items_scan_bins(u32 * __restrict__ waveCounts, u32 nWaves, u32 nBins, u32 * __restrict__ binTotals)
+// single thread: bin starts (from the exclusive scan of the bin-major count matrix) and the bin processing order of
+// sortedBins() — descending load, ties by bin number (reference src/d_mapper.h:843-854; std::sort leaves ties
+// unspecified) — as a rank per bin.
+__global__ void k_items_bin_starts(const u32 * __restrict__ waveOffsets, const u32 * __restrict__ total, u32 nWaves, u32 nBins,
+                                   u32 * __restrict__ binStart, u32 * __restrict__ binOrderRank)
 {
-    const u32 bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= nBins) return;
-    u32 * row = waveCounts + (size_t)bin * nWaves;
-    u32 run = 0;
-    for (u32 i = 0; i < nWaves; ++i) { u32 c = row[i]; row[i] = run; run += c; }
-    binTotals[bin] = run;
-}
-
-// single thread: bin starts (exclusive scan) and the bin processing order of sortedBins() — descending load, ties by
-// bin number (reference src/d_mapper.h:843-854; std::sort leaves ties unspecified) — as a rank per bin.
-__global__ void k_items_bin_starts(const u32 * __restrict__ binTotals, u32 nBins, u32 * __restrict__ binStart, u32 * __restrict__ binOrderRank)
-{
-    if (blockIdx.x || threadIdx.x) return;
-    u32 run = 0;
-    for (u32 b = 0; b < nBins; ++b) { binStart[b] = run; run += binTotals[b]; }
-    binStart[nBins] = run;
-    for (u32 b = 0; b < nBins; ++b)
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nBins) return;
+    binStart[b] = b < nBins ? waveOffsets[(size_t)b * nWaves] : *total;
+    if (b == nBins) return;
+    auto load = [&](u32 x) { return (x + 1 < nBins ? waveOffsets[(size_t)(x + 1) * nWaves] : *total) - waveOffsets[(size_t)x * nWaves]; };
+    const u32 mine = load(b);
+    u32 r = 0;
+    for (u32 o = 0; o < nBins; ++o)
     {
-        u32 r = 0;
-        for (u32 o = 0; o < nBins; ++o)
-            if (binTotals[o] > binTotals[b] || (binTotals[o] == binTotals[b] && o < b)) ++r;
-        binOrderRank[b] = r;
+        const u32 t = load(o);
+        if (t > mine || (t == mine && o < b)) ++r;
     }
+    binOrderRank[b] = r;
 }
 
 __global__ void k_items_scatter(const u64 * __restrict__ masks, u32 nReads, u32 W, u32 nBins, const u32 * __restrict__ waveOffsets,
-                                const u32 * __restrict__ binStart, u32 * __restrict__ itemRead, u16 * __restrict__ itemBin)
+                                u32 * __restrict__ itemRead, u16 * __restrict__ itemBin)
 {
     const u32 gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const u32 read = gw * 64 + lane;
@@ -122,7 +115,7 @@ __global__ void k_items_scatter(const u64 * __restrict__ masks, u32 nReads, u32 
             if (mine)
             {
                 u32 rank = __popcll(b & ((1ull << lane) - 1));
-                u32 dst = binStart[bin] + waveOffsets[(size_t)bin * nWaves + gw] + rank;
+                u32 dst = waveOffsets[(size_t)bin * nWaves + gw] + rank;      // global offset: the matrix is scanned bin-major
                 itemRead[dst] = read;
                 itemBin[dst] = (u16)bin;
             }
