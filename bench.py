@@ -37,11 +37,6 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def shard_reads(n_total_per_rank, rank):
-    """Weak scaling: every rank simulates its own batch; the seed differs per rank (SURVEY.md §8d seeds + rank)."""
-    return 0x5EED0000 + 2 + 1000 * rank
-
-
 def build_inputs(wl, work_dir, rank, world, barrier):
     """Setup (untimed): genomes, index files (rank 0 builds, all load), reads. Returns (genomes, index_dir)."""
     from dream_yara_amd import synth
@@ -94,8 +89,7 @@ def main():
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from dream_yara_amd.dist import Group, shard_seed, whole_job_rate
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -103,16 +97,9 @@ def main():
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
 
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    grp = Group("nccl" if world > 1 else None)
+    rank, local_rank = grp.rank, grp.local_rank
+    barrier = grp.barrier
 
     import dream_yara_amd as dy
     from dream_yara_amd import synth, build as dybuild
@@ -135,7 +122,7 @@ def main():
     log("rank %d: filter built on device + index uploaded in %.1f s" % (rank, time.time() - t0))
 
     t0 = time.time()
-    codes, offs, truth = synth.simulate_reads(genomes, wl["reads"], wl["L"], seed=shard_reads(wl["reads"], rank))
+    codes, offs, truth = synth.simulate_reads(genomes, wl["reads"], wl["L"], seed=shard_seed(2, rank))
     reads = dy.Reads(ctx, codes, offs)
     del genomes
     log("rank %d: %d reads simulated + uploaded in %.1f s" % (rank, wl["reads"], time.time() - t0))
@@ -167,11 +154,7 @@ def main():
         else:
             last = r
     ctx.sync(); torch.cuda.synchronize() if torch.cuda.is_available() else None; barrier()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
 
     # correctness spot-check of the last step against the simulation truth (not timed)
     rr = last.fetch().reads()
@@ -183,8 +166,7 @@ def main():
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = 1e3 * elapsed / steps
-        total_reads = wl["reads"] * world * steps
-        value = total_reads / elapsed
+        value = whole_job_rate(wl["reads"], steps, world, elapsed)
         # roofline of the dominant HBM kernel K1: algorithmic bytes = strands * (L-k+1) * h * W * 8 B per read
         W = (wl["bins"] + 63) // 64
         bytes_per_read = 2 * (wl["L"] - wl["k"] + 1) * wl["h"] * W * 8
@@ -221,8 +203,7 @@ def main():
         print(json.dumps(out), flush=True)
     barrier()
     reads.close(); index.close(); ibf.close(); ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -145,7 +145,7 @@ __global__ void k_fill_masks(u64 * masks, u32 nReads, u32 W, u32 nBins)
 template <int NW>
 static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink)
 {
-    hipLaunchKernelGGL(k_extend<NW>, dim3((nItems + 255) / 256), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+    hipLaunchKernelGGL(k_extend<NW>, dim3(((nItems + 255) / 256 + 7) / 8 * 8), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
                        nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2);
 }
 
@@ -467,7 +467,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         if (nItems)
         {
             u64 threads = (u64)nItems * 2 * S0;
-            hipLaunchKernelGGL(k_seed_search, dim3((u32)((threads + 255) / 256)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+            hipLaunchKernelGGL(k_seed_search, dim3((u32)(((threads + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
                                nItems, S0, mp.errorRate, ctx->hits0.as<uint2>());
         }
         HIP_CHECK(hipEventRecord(ctx->ev[4], st));

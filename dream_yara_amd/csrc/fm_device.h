@@ -95,12 +95,32 @@ __device__ __forceinline__ u32 bwtSymbol(const BinView & b, u32 row)
     return (word >> sh) & 3;
 }
 
-// one backward-search step on both range ends; false when the range becomes empty
+// one backward-search step on both range ends; false when the range becomes empty.
+// Once the range is narrow both ends fall into the same 64-symbol block: it is fetched once.
 __device__ __forceinline__ bool fmStep(const BinView & b, u32 & lo, u32 & hi, u32 c)
 {
-    lo = lfMap(b, lo, c);
-    hi = lfMap(b, hi, c);
+    const uint4 * blkLo = b.rank + (size_t)(lo >> 6) * 2;
+    const uint4 symLo = blkLo[0], cntLo = blkLo[1];
+    uint4 symHi = symLo, cntHi = cntLo;
+    if ((hi >> 6) != (lo >> 6))
+    {
+        const uint4 * blkHi = b.rank + (size_t)(hi >> 6) * 2;
+        symHi = blkHi[0]; cntHi = blkHi[1];
+    }
+    u32 rl = sel4(cntLo, c) + countInBlock(symLo, c, lo & 63);
+    u32 rh = sel4(cntHi, c) + countInBlock(symHi, c, hi & 63);
+    if (c == b.drs) { rl -= sentinelsBefore(b, lo); rh -= sentinelsBefore(b, hi); }
+    lo = b.pst[c] + rl;
+    hi = b.pst[c] + rh;
     return lo < hi;
+}
+
+// XCD-aware block remap: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share an L2), so give every XCD
+// one contiguous eighth of the (bin-major) work list: its 4 MiB L2 then holds the rank blocks of the bin it is walking.
+__device__ __forceinline__ u32 xcdRemapBlock(u32 blockId, u32 nBlocks)
+{
+    const u32 per = (nBlocks + 7) / 8;
+    return (blockId % 8) * per + blockId / 8;
 }
 
 // SA[row] -> (contig, offset in the REVERSED contig)

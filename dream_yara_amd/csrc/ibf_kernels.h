@@ -80,43 +80,66 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
 
     u64 selOwn = 0;   // selected bins: lane l owns mask word l (W <= 64)
 
+    // Pruning that cannot change the result: once every bin is decided (count >= threshold, or count + remaining <
+    // threshold) the remaining k-mers are not looked up.  The last `tail` k-mers (at most threshold-2, so that a bin
+    // with a single stray hit is already decided) form their own chunk; for reads that really come from one bin this
+    // skips about a third of the gathers of both strands.
+    const u32 tail = threshold >= 2 ? min(min(threshold - 2, 64u), nKmers) : 0;
+    const u32 head = nKmers - tail;
+
     for (u32 strand = 0; strand < 2; ++strand)
     {
         for (u32 b = lane; b < 64 * g.W; b += 64) counts[b] = 0;
         const bool firstIsN = strandCode(seq, len, 0, strand) > 3;     // SeqAn hashInit takes text[0] uncast
-        for (u32 base = 0; base < nKmers; base += 64)
+        u32 base = 0, limit = head;
+        for (u32 phase = 0; phase < 2; ++phase)
         {
-            // bit planes of bases [base, base+128)
-            u32 c0 = strandCode(seq, len, base + lane, strand), c1 = strandCode(seq, len, base + 64 + lane, strand);
-            if (c0 > 3) c0 = 0;
-            if (c1 > 3) c1 = 0;
-            const u64 p0lo = ballot64(c0 & 1), p1lo = ballot64(c0 & 2), p0hi = ballot64(c1 & 1), p1hi = ballot64(c1 & 2);
-            const u32 i = base + lane;
-            const bool valid = i < nKmers;
-            // bits [lane, lane+k) of the 128-bit planes
-            u64 x0 = lane ? ((p0lo >> lane) | (p0hi << (64 - lane))) : p0lo;
-            u64 x1 = lane ? ((p1lo >> lane) | (p1hi << (64 - lane))) : p1lo;
-            x0 &= kMask; x1 &= kMask;
-            // base t of the k-mer carries weight 4^(k-1-t): reverse the k bits, then interleave the planes
-            u64 r0 = __brevll(x0) >> (64 - k), r1 = __brevll(x1) >> (64 - k);
-            u64 hash = spreadBits(r0) | (spreadBits(r1) << 1);
-            if (firstIsN && 2 * (k + i) < 64) hash += 1ull << (2 * (k + i));
-
-            for (u32 w = 0; w < g.W; ++w)
+            if (phase == 1)
             {
-                u64 m = 0;
-                if (valid)
+                if (!tail) break;
+                bool undecided = false;
+                for (u32 w = 0; w < g.W; ++w)
                 {
-                    m = ~0ull;
-                    for (u32 hf = 0; hf < g.nHashes; ++hf) m &= words[ibfWordIndex(g, hash, hf) + w];
+                    const u32 c = counts[w * 64 + lane];
+                    undecided |= __ballot(c < threshold && c + tail >= threshold) != 0;
                 }
-                u64 cand = waveOr64(m);
-                while (cand)
+                if (!undecided) break;
+                base = head; limit = nKmers;
+            }
+            for (; base < limit; base += 64)
+            {
+                // bit planes of bases [base, base+128)
+                u32 c0 = strandCode(seq, len, base + lane, strand), c1 = strandCode(seq, len, base + 64 + lane, strand);
+                if (c0 > 3) c0 = 0;
+                if (c1 > 3) c1 = 0;
+                const u64 p0lo = ballot64(c0 & 1), p1lo = ballot64(c0 & 2), p0hi = ballot64(c1 & 1), p1hi = ballot64(c1 & 2);
+                const u32 i = base + lane;
+                const bool valid = i < limit;
+                // bits [lane, lane+k) of the 128-bit planes
+                u64 x0 = lane ? ((p0lo >> lane) | (p0hi << (64 - lane))) : p0lo;
+                u64 x1 = lane ? ((p1lo >> lane) | (p1hi << (64 - lane))) : p1lo;
+                x0 &= kMask; x1 &= kMask;
+                // base t of the k-mer carries weight 4^(k-1-t): reverse the k bits, then interleave the planes
+                u64 r0 = __brevll(x0) >> (64 - k), r1 = __brevll(x1) >> (64 - k);
+                u64 hash = spreadBits(r0) | (spreadBits(r1) << 1);
+                if (firstIsN && 2 * (k + i) < 64) hash += 1ull << (2 * (k + i));
+
+                for (u32 w = 0; w < g.W; ++w)
                 {
-                    u32 j = __ffsll((long long)cand) - 1;
-                    cand &= cand - 1;
-                    u32 cnt = __popcll(ballot64((m >> j) & 1));
-                    if (lane == 0) counts[w * 64 + j] += (u16)cnt;
+                    u64 m = 0;
+                    if (valid)
+                    {
+                        m = ~0ull;
+                        for (u32 hf = 0; hf < g.nHashes; ++hf) m &= words[ibfWordIndex(g, hash, hf) + w];
+                    }
+                    u64 cand = waveOr64(m);
+                    while (cand)
+                    {
+                        u32 j = __ffsll((long long)cand) - 1;
+                        cand &= cand - 1;
+                        u32 cnt = __popcll(ballot64((m >> j) & 1));
+                        if (lane == 0) counts[w * 64 + j] += (u16)cnt;
+                    }
                 }
             }
         }

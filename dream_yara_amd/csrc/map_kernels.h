@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
                                                      const u16 * __restrict__ itemBin, u32 nItems, u32 S0, float errorRate,
                                                      uint2 * __restrict__ hits0)
 {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 t = (u64)xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const u32 slots = 2 * S0;
     const u32 item = (u32)(t / slots), slot = (u32)(t % slots);
     if (item >= nItems) return;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, cons
                                                 u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
                                                 u32 * __restrict__ hardItems)
 {
-    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 item = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     if (item >= nItems) return;
     const u32 read = itemRead[item], bin = itemBin[item];
     const u8 * seq = rd.seqs + rd.offs[read];
