@@ -38,6 +38,8 @@ struct BinDesc
     u32 drs;             // sentinel substitute symbol (lf.drs)
     u32 drpOff;          // first sentinel row (lf.drp), nContigs entries, ascending
     u32 contigIdBase;    // global id of contig 0 of this bin (reference src/d_mapper.h:146)
+    u64 saFullOff;       // first row of this bin in the expanded suffix array (device-only, see k_expand_sa)
+    u64 prefixOff;       // first entry of this bin in the q-mer range table (device-only, see k_prefix_level)
 };
 
 // Raw extension result (reference src/bits_matches.h:116-127, unpacked; 16 B).

@@ -93,7 +93,7 @@ struct dy_reads
 {
     dy_ctx * ctx = nullptr;
     u32 n = 0; u64 totalBases = 0; u32 maxLen = 0; u32 minLen = 0;
-    DevBuf seqs, offs, masks;
+    DevBuf seqs, seqsRc, offs, masks;
     u32 maskW = 0;       // words per read currently held in masks (0 = none)
     u32 maskBins = 0;
 };
@@ -104,12 +104,17 @@ struct dy_index
     std::vector<BinDesc> bins;
     std::vector<std::string> contigNames;
     std::vector<u64> contigLengths;
-    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp;
+    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable;
+    bool hasFullSa = false, multiContig = false;
+    u32 prefixQ = 0;
     IndexView view() const
     {
         IndexView v;
         v.bins = dBins.as<BinDesc>(); v.rank = rank.as<uint4>(); v.ind = ind.as<uint2>(); v.valOffset = valOffset.as<u32>();
         v.valContig = valContig.as<u16>(); v.contigs = contigs.as<u8>(); v.limits = limits.as<u64>(); v.drp = drp.as<u32>();
+        v.saFullOffset = hasFullSa ? saFullOffset.as<u32>() : nullptr;
+        v.saFullContig = (hasFullSa && multiContig) ? saFullContig.as<u16>() : nullptr;
+        v.prefixTable = prefixQ ? prefixTable.as<uint2>() : nullptr; v.prefixQ = prefixQ;
         v.nBins = (u32)bins.size();
         return v;
     }
@@ -329,6 +334,9 @@ int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, u
         r->offs.reserve((size_t)(n_reads + 1) * 8);
         if (r->totalBases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs, r->totalBases, hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK(hipMemcpyAsync(r->offs.p, offs, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        r->seqsRc.reserve(r->totalBases + 64);
+        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
+        HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *out = r.release();
     });
@@ -382,8 +390,58 @@ int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** o
         std::unique_ptr<dy_index> idx(new dy_index);
         idx->ctx = ctx;
         idx->bins = H.bins; idx->contigNames = H.contigNames; idx->contigLengths = H.contigLengths;
+        u64 totalRows = 0;
+        for (auto & bd : H.bins) { bd.saFullOff = totalRows; totalRows += bd.n; idx->multiContig |= bd.nContigs > 1; }
+        idx->bins = H.bins;
         upload(idx->dBins, H.bins); upload(idx->rank, H.rank); upload(idx->ind, H.ind); upload(idx->valOffset, H.valOffset);
         upload(idx->valContig, H.valContig); upload(idx->contigs, H.contigs); upload(idx->limits, H.limits); upload(idx->drp, H.drp);
+        // expand the sparse SA when it fits comfortably (DY_SPARSE_SA=1 keeps the on-disk sampling, for comparison)
+        size_t freeB = 0, totalB = 0;
+        HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+        const size_t need = totalRows * (idx->multiContig ? 6 : 4) + 4096;
+        if (!getenv("DY_SPARSE_SA") && need < freeB / 2)
+        {
+            idx->saFullOffset.reserve(totalRows * 4 + 64);
+            if (idx->multiContig) idx->saFullContig.reserve(totalRows * 2 + 64);
+            IndexView v = idx->view();
+            for (u32 b = 0; b < n_bins; ++b)
+                hipLaunchKernelGGL(k_expand_sa, dim3((H.bins[b].n + 255) / 256), dim3(256), 0, ctx->stream, v, b, idx->saFullOffset.as<u32>(),
+                                   idx->multiContig ? idx->saFullContig.as<u16>() : nullptr);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            idx->hasFullSa = true;
+        }
+        // q-mer range table: as many levels as fit in a quarter of the free HBM, at most 12 (DY_PREFIX_Q overrides, 0 = off)
+        {
+            HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+            u32 q = 12;
+            while (q > 0 && ((size_t)n_bins << (2 * q)) * sizeof(uint2) > freeB / 4) --q;
+            if (getenv("DY_PREFIX_Q")) q = std::min<u32>(q, (u32)atoi(getenv("DY_PREFIX_Q")));
+            if (q >= 4)
+            {
+                const size_t perBin = (size_t)1 << (2 * q);
+                idx->prefixTable.reserve(perBin * n_bins * sizeof(uint2) + 64);
+                DevBuf ping, pong;
+                ping.reserve((perBin / 4) * sizeof(uint2) + 64); pong.reserve((perBin / 4) * sizeof(uint2) + 64);
+                for (u32 b = 0; b < n_bins; ++b) idx->bins[b].prefixOff = perBin * b;
+                upload(idx->dBins, idx->bins);
+                IndexView v = idx->view();
+                for (u32 b = 0; b < n_bins; ++b)
+                {
+                    const uint2 * parent = nullptr;
+                    for (u32 level = 1; level <= q; ++level)
+                    {
+                        const u32 nChild = 1u << (2 * level);
+                        uint2 * child = level == q ? idx->prefixTable.as<uint2>() + perBin * b : ((level & 1) ? ping.as<uint2>() : pong.as<uint2>());
+                        hipLaunchKernelGGL(k_prefix_level, dim3((nChild + 255) / 256), dim3(256), 0, ctx->stream, v, b, parent, child, nChild);
+                        parent = child;
+                    }
+                }
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                idx->prefixQ = q;
+            }
+        }
         *out = idx.release();
     });
 }
@@ -461,7 +519,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
 
         // ---- K2: exact search of the round-0 seeds
         const IndexView ix = idx->view();
-        ReadsView rv; rv.seqs = reads->seqs.as<u8>(); rv.offs = reads->offs.as<u64>(); rv.nReads = nReads;
+        ReadsView rv; rv.seqs = reads->seqs.as<u8>(); rv.seqsRc = reads->seqsRc.as<u8>(); rv.offs = reads->offs.as<u64>(); rv.nReads = nReads;
         MapParams mp; mp.errorRate = p->error_rate; mp.strataRate = p->strata_rate; mp.sensitivity = p->sensitivity; mp.hitsThreshold = p->hits_threshold;
         ctx->hits0.reserve((size_t)nItems * 2 * S0 * sizeof(uint2) + 64);
         if (nItems)
@@ -483,7 +541,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
             ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
             HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 16, st));
             HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
-            MatchSink sink; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
+            MatchSink sink; sink.debugFlags = getenv("DY_DEBUG_EXTEND") ? (u32)atoi(getenv("DY_DEBUG_EXTEND")) : 0; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
             sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
             if (nItems)
             {

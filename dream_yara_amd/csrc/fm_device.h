@@ -19,6 +19,10 @@ struct IndexView
     const u8 *      contigs;
     const u64 *     limits;
     const u32 *     drp;
+    const u32 *     saFullOffset;   // expanded SA (one entry per BWT row) or nullptr: then the sparse SA is walked
+    const u16 *     saFullContig;   // nullptr when every bin has a single contig
+    const uint2 *   prefixTable;    // per bin 4^q (lo,hi) ranges of every q-mer, or nullptr
+    u32             prefixQ;
     u32             nBins;
 };
 
@@ -31,6 +35,8 @@ struct BinView
     const u8 *    contigs;      // base of this bin's concatenated contigs
     const u64 *   limits;       // nContigs + 1
     const u32 *   drp;
+    const u32 *   saFullOffset;
+    const u16 *   saFullContig;
     u32 n, nContigs, drs;
     u32 pst[4];
 };
@@ -46,6 +52,8 @@ __device__ __forceinline__ BinView makeBinView(const IndexView & ix, u32 bin)
     b.contigs = ix.contigs + d.contigOff;
     b.limits = ix.limits + d.limOff;
     b.drp = ix.drp + d.drpOff;
+    b.saFullOffset = ix.saFullOffset ? ix.saFullOffset + d.saFullOff : nullptr;
+    b.saFullContig = ix.saFullContig ? ix.saFullContig + d.saFullOff : nullptr;
     b.n = d.n; b.nContigs = d.nContigs; b.drs = d.drs;
     b.pst[0] = d.pst[0]; b.pst[1] = d.pst[1]; b.pst[2] = d.pst[2]; b.pst[3] = d.pst[3];
     return b;
@@ -123,8 +131,8 @@ __device__ __forceinline__ u32 xcdRemapBlock(u32 blockId, u32 nBlocks)
     return (blockId % 8) * per + blockId / 8;
 }
 
-// SA[row] -> (contig, offset in the REVERSED contig)
-__device__ __forceinline__ void fmLocate(const BinView & b, u32 row, u32 & contig, u32 & offset)
+// SA[row] -> (contig, offset in the REVERSED contig) by walking LF to the next sampled row (SeqAn CompressedSA)
+__device__ __forceinline__ void fmLocateSparse(const BinView & b, u32 row, u32 & contig, u32 & offset)
 {
     u32 steps = 0;
     for (;;)
@@ -141,6 +149,51 @@ __device__ __forceinline__ void fmLocate(const BinView & b, u32 row, u32 & conti
         row = lfMap(b, row, bwtSymbol(b, row));
         ++steps;
     }
+}
+
+// With 288 GB of HBM the sparse SA (one sample per 10 text positions on disk) is expanded once at load time to one
+// entry per row, so a locate on the mapping path is a single load instead of up to 9 dependent LF steps.
+__device__ __forceinline__ void fmLocate(const BinView & b, u32 row, u32 & contig, u32 & offset)
+{
+    if (b.saFullOffset)
+    {
+        offset = b.saFullOffset[row];
+        contig = b.saFullContig ? b.saFullContig[row] : 0;
+        return;
+    }
+    fmLocateSparse(b, row, contig, offset);
+}
+
+// Range table of all q-mers of one bin, built level by level at load time: entry(p·4 + c) = step(entry(p), c).
+// On the mapping path one gather replaces the first q backward-search steps of a seed (the ones whose two range ends
+// still sit in different rank blocks).
+__global__ void k_prefix_level(IndexView ix, u32 bin, const uint2 * __restrict__ parent, uint2 * __restrict__ child, u32 nChild)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nChild) return;
+    const BinView b = makeBinView(ix, bin);
+    uint2 r = parent ? parent[i >> 2] : make_uint2(0u, b.n);
+    if (r.x < r.y)
+    {
+        u32 lo = r.x, hi = r.y;
+        r = fmStep(b, lo, hi, i & 3) ? make_uint2(lo, hi) : make_uint2(0u, 0u);
+    }
+    else r = make_uint2(0u, 0u);
+    child[i] = r;
+}
+
+__global__ void k_expand_sa(IndexView ix, u32 bin, u32 * __restrict__ outOffset, u16 * __restrict__ outContig)
+{
+    BinView b = makeBinView(ix, bin);
+    b.saFullOffset = nullptr;
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= b.n) return;
+    u32 contig = 0, offset = 0;
+    // the first nContigs rows are the suffixes "$c": they never occur in a hit range and carry no sample
+    if (row >= b.nContigs) fmLocateSparse(b, row, contig, offset);
+    const u64 base = ix.bins[bin].saFullOff;
+    outOffset[base + row] = offset;
+    if (outContig) outContig[base + row] = (u16)contig;
 }
 
 } // namespace dy

@@ -18,9 +18,62 @@ namespace dy {
 struct ReadsView
 {
     const u8 *  seqs;     // forward reads, Dna5 codes
+    const u8 *  seqsRc;   // reverse complements, same offsets (appendReverseComplement, reference src/store_seqs.h:271-290)
     const u64 * offs;     // nReads + 1
     u32         nReads;
 };
+
+// one thread per read writes its reverse complement
+__global__ void k_revcomp_reads(const u8 * __restrict__ fwd, u8 * __restrict__ rc, const u64 * __restrict__ offs, u32 nReads)
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nReads) return;
+    const u64 o = offs[r];
+    const u32 len = (u32)(offs[r + 1] - o);
+    for (u32 i = 0; i < len; ++i) { const u8 c = fwd[o + len - 1 - i]; rc[o + i] = c < 4 ? (u8)(3 - c) : c; }
+}
+
+// ---- 8-bytes-at-a-time comparison of Dna5 code strings (N = 4 never matches, reference src/basic_alphabet.h:47) ----
+struct __attribute__((packed)) PackedU64 { u64 v; };
+__device__ __forceinline__ u64 load8(const u8 * p) { return ((const PackedU64 *)p)->v; }
+// bit 8*i set iff byte i differs or holds an N on either side
+__device__ __forceinline__ u64 mismatchFlags(u64 a, u64 b)
+{
+    u64 x = (a ^ b) | ((a | b) & 0x0404040404040404ull);
+    x |= (x >> 1) | (x >> 2);
+    return x & 0x0101010101010101ull;
+}
+// length of the common prefix of a[0..n) and b[0..n)
+__device__ __forceinline__ int lcpForward(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
+{
+    int i = 0;
+    for (; i + 8 <= n; i += 8)
+    {
+        const u64 f = mismatchFlags(load8(a + i), load8(b + i));
+        if (f) return i + (__ffsll((long long)f) - 1) / 8;
+    }
+    for (; i < n; ++i) { const u32 x = a[i], y = b[i]; if (!(x == y && x < 4)) break; }
+    return i;
+}
+// length of the common suffix of a[-n..0) and b[-n..0) (a, b point one past the last byte)
+__device__ __forceinline__ int lcpBackward(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
+{
+    int i = 0;
+    for (; i + 8 <= n; i += 8)
+    {
+        const u64 f = mismatchFlags(load8(a - i - 8), load8(b - i - 8));
+        if (f) return i + __clzll((long long)f) / 8;
+    }
+    for (; i < n; ++i) { const u32 x = a[-1 - i], y = b[-1 - i]; if (!(x == y && x < 4)) break; }
+    return i;
+}
+__device__ __forceinline__ u32 countMismatches(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
+{
+    u32 c = 0; int i = 0;
+    for (; i + 8 <= n; i += 8) c += (u32)__popcll(mismatchFlags(load8(a + i), load8(b + i)));
+    for (; i < n; ++i) { const u32 x = a[i], y = b[i]; c += !(x == y && x < 4); }
+    return c;
+}
 
 // base `pos` of the read sequence of `strand` (1 = reverse complement)
 __device__ __forceinline__ u32 readBase(const u8 * __restrict__ seq, u32 len, u32 strand, u32 pos)
@@ -145,10 +198,18 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
     if (seedId < cnt && len >= cnt)
     {
         const u32 seedLen = len / cnt, off = (cnt - 1 - seedId) * seedLen;
-        BinView b = makeBinView(ix, itemBin[item]);
-        u32 lo = 0, hi = b.n;
+        const u32 bin = itemBin[item];
+        BinView b = makeBinView(ix, bin);
+        u32 lo = 0, hi = b.n, d0 = 0;
         bool ok = true;
-        for (u32 d = 0; d < seedLen && ok; ++d)
+        if (ix.prefixTable && seedLen >= ix.prefixQ)
+        {   // first q characters through the q-mer table
+            u32 idx = 0;
+            for (u32 d = 0; d < ix.prefixQ; ++d) { const u32 c = readBase(seq, len, strand, off + d); ok &= c < 4; idx = idx * 4 + (c & 3); }
+            if (ok) { const uint2 r = ix.prefixTable[ix.bins[bin].prefixOff + idx]; lo = r.x; hi = r.y; ok = lo < hi; }
+            d0 = ix.prefixQ;
+        }
+        for (u32 d = d0; d < seedLen && ok; ++d)
         {
             u32 c = readBase(seq, len, strand, off + d);
             ok = c < 4 && fmStep(b, lo, hi, c);          // N never matches (reference src/index_fm.h:147)
@@ -232,6 +293,7 @@ struct ItemState
 
 struct MatchSink
 {
+    u32 debugFlags;    // DY_DEBUG_EXTEND (timing experiments only): 1 = stop after locate, 2 = stop before locate
     RawMatch * pool;
     u32 *      poolCount;
     u32        poolCap;
@@ -240,6 +302,7 @@ struct MatchSink
 };
 
 // extend() + _addMatchImpl() for one located seed occurrence (reference src/find_extender.h:262-403, src/mapper_extender.h:293-308).
+// `seq` is the read sequence of the seed's strand (forward or reverse complement), readable front to back.
 template <int NW>
 __device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u32 seedLen, const u8 * __restrict__ seq, u32 len, u32 strand,
                                  u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
@@ -247,30 +310,17 @@ __device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u3
     const u8 * __restrict__ ctg = b.contigs + b.limits[contig];
     const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
     const u32 hayEnd = hayBegin + seedLen, needleEnd = needleBegin + seedLen;
-    u32 errors = 0;
-    // _checkSeed: recount against the real contig (Ns were randomised in the index)
-    {
-        u32 d = 0;
-        for (; d < seedLen && errors <= maxErrors; ++d)
-        {
-            u32 h = ctg[hayBegin + d], q = readBase(seq, len, strand, needleBegin + d);
-            errors += !(h == q && h < 4);
-        }
-        if (!(d == seedLen && errors <= maxErrors)) return;
-    }
+    // _checkSeed: recount against the real contig (Ns were randomised in the index); the early-out of the reference's
+    // loop only matters when the total exceeds maxErrors, which fails either way
+    u32 errors = countMismatches(ctg + hayBegin, seq + needleBegin, (int)seedLen);
+    if (errors > maxErrors) return;
     u32 matchBegin = hayBegin;
     if (needleBegin > 0)
     {   // _extendLeft on the reversed infixes
         const u32 leftOffset = needleBegin + (maxErrors - errors);
         const u32 leftBegin = hayBegin > leftOffset ? hayBegin - leftOffset : 0;
         const int hayLen = (int)(hayBegin - leftBegin), ndlLen = (int)needleBegin;
-        int lcp = 0;
-        while (lcp < hayLen && lcp < ndlLen)
-        {
-            u32 h = ctg[hayBegin - 1 - lcp], q = readBase(seq, len, strand, needleBegin - 1 - lcp);
-            if (!(h == q && h < 4)) break;
-            ++lcp;
-        }
+        const int lcp = lcpBackward(ctg + hayBegin, seq + needleBegin, hayLen < ndlLen ? hayLen : ndlLen);
         if (lcp == ndlLen)
             matchBegin -= lcp;
         else
@@ -280,7 +330,7 @@ __device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u3
             u32 minErr = remaining + 1;
             int endPos = 0;
             const u32 hb = hayBegin - 1 - lcp, nb = needleBegin - 1 - lcp;
-            myersPrefixSearch<NW>([&](int i) { return readBase(seq, len, strand, nb - i); }, ndlLen - lcp,
+            myersPrefixSearch<NW>([&](int i) { return (u32)seq[nb - i]; }, ndlLen - lcp,
                                   [&](int j) { return (u32)ctg[hb - j]; }, hayLen - lcp, (int)remaining,
                                   [&](int pos, int dist) { if ((u32)dist <= minErr) { minErr = (u32)dist; endPos = pos + 1; } });
             errors += minErr;
@@ -295,13 +345,7 @@ __device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u3
         u32 rightEnd = clen;
         if (rightEnd > hayBegin + rightOffset) rightEnd = hayBegin + rightOffset;
         const int hayLen = (int)(rightEnd - hayEnd), ndlLen = (int)(len - needleEnd);
-        int lcp = 0;
-        while (lcp < hayLen && lcp < ndlLen)
-        {
-            u32 h = ctg[hayEnd + lcp], q = readBase(seq, len, strand, needleEnd + lcp);
-            if (!(h == q && h < 4)) break;
-            ++lcp;
-        }
+        const int lcp = lcpForward(ctg + hayEnd, seq + needleEnd, hayLen < ndlLen ? hayLen : ndlLen);
         if (lcp == ndlLen)
             matchEnd += lcp;
         else if (lcp == hayLen)
@@ -318,8 +362,8 @@ __device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u3
             int endPos = 0;
             const u32 hb = hayEnd + lcp, nb = needleEnd + lcp;
             const int hl = hayLen - lcp, nl = ndlLen - lcp;
-            const u32 lastNeedle = readBase(seq, len, strand, nb + nl - 1);
-            myersPrefixSearch<NW>([&](int i) { return readBase(seq, len, strand, nb + i); }, nl - 1,
+            const u32 lastNeedle = seq[nb + nl - 1];
+            myersPrefixSearch<NW>([&](int i) { return (u32)seq[nb + i]; }, nl - 1,
                                   [&](int j) { return (u32)ctg[hb + j]; }, hl - 1, (int)remaining,
                                   [&](int pos, int dist) {
                                       const int currentEnd = pos + 1;
@@ -354,10 +398,12 @@ template <int NW>
 __device__ void extendRange(const BinView & b, u32 lo, u32 hi, u32 seedLen, const u8 * __restrict__ seq, u32 len, u32 strand,
                             u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
 {
+    if (sink.debugFlags & 2) return;
     for (u32 row = lo; row < hi; ++row)
     {
         u32 contig, x;
         fmLocate(b, row, contig, x);
+        if (sink.debugFlags & 1) { if (x == 0xFFFFFFFFu) st.minErrors = 0; continue; }
         const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
         if (clen - x < seedLen) continue;                       // suffixLength < seedLength
         extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, seq, len, strand, needleBegin, maxErrors, read, bin, st, sink);
@@ -410,6 +456,7 @@ __global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, cons
     if (item >= nItems) return;
     const u32 read = itemRead[item], bin = itemBin[item];
     const u8 * seq = rd.seqs + rd.offs[read];
+    const u8 * seqRc = rd.seqsRc + rd.offs[read];
     const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
     const u32 readErrors = readErrorsOf(len, prm.errorRate), readStrata = readStrataOf(len, prm.strataRate);
     const BinView b = makeBinView(ix, bin);
@@ -444,7 +491,7 @@ __global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, cons
                     }
                     done[strand] |= 1u << bestId;
                     uint2 r = h0[strand * S0 + bestId];
-                    extendRange<NW>(b, r.x, r.y, seedLen, seq, len, strand, (cnt0 - 1 - bestId) * seedLen, readErrors, read, bin, st, sink);
+                    extendRange<NW>(b, r.x, r.y, seedLen, strand ? seqRc : seq, len, strand, (cnt0 - 1 - bestId) * seedLen, readErrors, read, bin, st, sink);
                 }
                 if (st.minErrors + readStrata <= rank) st.mapped = true;     // seedErrors = 0: rank * (0 + 1)
             }
@@ -485,7 +532,7 @@ __global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, cons
                 done[strand] |= 1u << bestId;
                 const u32 off = (cntB - 1 - bestId) * seedLen;
                 fmBacktrack(b, seq, len, strand, off, seedLen, E, [&](u32 lo, u32 hi) {
-                    extendRange<NW>(b, lo, hi, seedLen, seq, len, strand, off, readErrors, read, bin, st, sink);
+                    extendRange<NW>(b, lo, hi, seedLen, strand ? seqRc : seq, len, strand, off, readErrors, read, bin, st, sink);
                 });
             }
             if (st.minErrors + readStrata <= rank * (E + 1)) st.mapped = true;
