@@ -76,7 +76,7 @@ struct dy_ctx
     dy_map_stats stats = {};
     bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
-    DevBuf waveCounts, waveOffsets, complexList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
+    DevBuf waveCounts, waveOffsets, complexList, alignList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp;
     size_t poolCap = 0;
 };
@@ -539,7 +539,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         for (;;)
         {
             ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
-            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 16, st));
+            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 32, st));
             HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
             MatchSink sink; sink.debugFlags = getenv("DY_DEBUG_EXTEND") ? (u32)atoi(getenv("DY_DEBUG_EXTEND")) : 0; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
             sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
@@ -591,7 +591,11 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         ctx->complexList.reserve((size_t)nReads * 4 + 64);
         u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
         fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
-        hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount);
+        ctx->alignList.reserve((size_t)nReads * 4 + 64);
+        u32 * alignCount = ctx->counters.as<u32>() + 4;
+        hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
+                           ctx->alignList.as<u32>(), alignCount);
+        hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
         hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));

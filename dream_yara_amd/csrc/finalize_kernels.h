@@ -695,7 +695,17 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
 
 // Fast path, one thread per read: a read without matches is unmapped; a read whose only match is ungapped needs no
 // sorting, no alignment and has X0 = 1, X1 = 0.  Everything else is queued for k_finalize.
-__global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount)
+__device__ __forceinline__ void writeSingleMatch(const FinalizeArgs & A, u32 read, ReadOut & ro, const RawMatch & a)
+{
+    OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
+    A.outSet[(size_t)ro.setBegin] = om;
+    ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
+    ro.mapped = om.length != 0; ro.bestCount = 1; ro.subCount = 0;
+    A.out[read] = ro;
+}
+
+__global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount,
+                                  u32 * __restrict__ alignList, u32 * __restrict__ alignCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
     if (read >= A.nReads) return;
@@ -703,34 +713,46 @@ __global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList
     const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
     ReadOut ro; ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
     ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
+    if (n == 0) { A.out[read] = ro; return; }
     if (n == 1)
     {
-        RawMatch a = A.gp[s0];
+        const RawMatch a = A.gp[s0];
         const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
-        const bool inThread = !gapped || (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E && !(A.debugFlags & 2));
-        if (inThread)
+        if (!gapped)
         {
-            if (gapped)
-            {   // alignMatches of the only match: CIGAR + shrink (reference src/mapper_aligner.h:204-236)
-                const BinDesc & bd = A.bins[a.bin];
-                const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
-                int cb, ce;
-                const u32 nc = alignMatchThread(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
-                                                A.cigars + ro.cigarBegin, A.cigarStride, cb, ce);
-                ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
-                a.begin += (u32)cb; a.len = (u16)ce;
-            }
-            else { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
-            OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
-            A.outSet[(size_t)ro.setBegin] = om;
-            ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
-            ro.mapped = om.length != 0; ro.bestCount = 1; ro.subCount = 0;
-            A.out[read] = ro;
+            A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1;
+            writeSingleMatch(A, read, ro, a);
+            return;
+        }
+        if (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
+        {   // alignment needed, but nothing to sort: queue for k_align_single (all lanes busy there)
+            alignList[atomicAdd(alignCount, 1u)] = read;
             return;
         }
     }
-    if (n == 0) { A.out[read] = ro; return; }
     complexList[atomicAdd(complexCount, 1u)] = read;
+}
+
+// alignMatches for reads whose only match needs the DP: CIGAR + shrink (reference src/mapper_aligner.h:204-236)
+__global__ __launch_bounds__(256) void k_align_single(FinalizeArgs A, const u32 * __restrict__ alignList, const u32 * __restrict__ alignCount)
+{
+    const u32 nList = *alignCount;
+    for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
+    {
+        const u32 read = alignList[li];
+        const u32 s0 = A.readStart[read];
+        const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+        ReadOut ro; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride;
+        RawMatch a = A.gp[s0];
+        const BinDesc & bd = A.bins[a.bin];
+        const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+        int cb, ce;
+        const u32 nc = alignMatchThread(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
+                                        A.cigars + ro.cigarBegin, A.cigarStride, cb, ce);
+        ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+        a.begin += (u32)cb; a.len = (u16)ce;
+        writeSingleMatch(A, read, ro, a);
+    }
 }
 
 // readStart-based regrouping of the raw pool

@@ -289,6 +289,10 @@ struct ItemState
 {
     u32 minErrors;     // 255 = none yet (ReadsContext::minErrors, reference src/bits_context.h:86)
     bool mapped;
+    // the first two matches of an item are kept in registers and appended with ONE pool reservation per wavefront at
+    // the end of the kernel (a single shared counter saturates at ~10^8 atomics/s); further matches go straight to the pool
+    RawMatch buf0, buf1;
+    u32 nbuf;
 };
 
 struct MatchSink
@@ -379,17 +383,17 @@ __device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u3
         }
     }
     // _addMatchImpl
-    const u32 slot = atomicAdd(sink.poolCount, 1u);
-    if (slot < sink.poolCap)
-    {
-        RawMatch m;
-        m.read = read; m.begin = matchBegin; m.len = (u16)(matchEnd - matchBegin); m.errors = (u8)errors; m.strand = (u8)strand;
-        m.bin = (u16)bin; m.contig = (u16)contig;
-        sink.pool[slot] = m;
-        atomicAdd(&sink.readMatchCount[read], 1u);
-    }
+    RawMatch m;
+    m.read = read; m.begin = matchBegin; m.len = (u16)(matchEnd - matchBegin); m.errors = (u8)errors; m.strand = (u8)strand;
+    m.bin = (u16)bin; m.contig = (u16)contig;
+    if (st.nbuf == 0) { st.buf0 = m; st.nbuf = 1; }
+    else if (st.nbuf == 1) { st.buf1 = m; st.nbuf = 2; }
     else
-        atomicExch(sink.overflow, 1u);
+    {
+        const u32 slot = atomicAdd(sink.poolCount, 1u);
+        if (slot < sink.poolCap) { sink.pool[slot] = m; atomicAdd(&sink.readMatchCount[read], 1u); }
+        else atomicExch(sink.overflow, 1u);
+    }
     if (errors < st.minErrors) st.minErrors = errors;
 }
 
@@ -448,56 +452,79 @@ __device__ void fmBacktrack(const BinView & b, const u8 * __restrict__ seq, u32 
 // K3: one thread per work item runs the read-local remainder of _mapReadsImpl.
 // ---------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
-                                                u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
-                                                u32 * __restrict__ hardItems)
+__device__ void extendItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
+                           const uint2 * __restrict__ hits0, const MatchSink & sink, u32 * __restrict__ hardItems, ItemState & st, bool valid)
 {
-    const u32 item = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    if (item >= nItems) return;
-    const u32 read = itemRead[item], bin = itemBin[item];
-    const u8 * seq = rd.seqs + rd.offs[read];
-    const u8 * seqRc = rd.seqsRc + rd.offs[read];
-    const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
-    const u32 readErrors = readErrorsOf(len, prm.errorRate), readStrata = readStrataOf(len, prm.strataRate);
-    const BinView b = makeBinView(ix, bin);
-    ItemState st; st.minErrors = 255; st.mapped = false;
-    const uint2 * h0 = hits0 + (size_t)item * 2 * S0;
-
-    // ---- classifyReads (reference src/mapper_classifier.h:111-155)
-    const u32 cnt0 = seedCountOf(readErrors, 0);
-    u64 total = 0;
-    for (u32 s = 0; s < 2 * S0; ++s) total += h0[s].y - h0[s].x;
-    u32 seedErrors = 0;
-    if (total > prm.hitsThreshold) seedErrors = (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
-
-    if (seedErrors == 0)
+    const u8 * seq = nullptr, * seqRc = nullptr;
+    u32 len = 0, readErrors = 0, readStrata = 0, cnt0 = 1, seedErrors = 0;
+    BinView b;
+    const uint2 * h0 = hits0;
+    if (valid)
     {
-        // ---- rankSeeds + extendHits<0>(bucket 0): seeds by ascending hit count, ties keep ascending seed id
-        if (len >= cnt0)
-        {
-            const u32 seedLen = len / cnt0;
-            u32 done[2] = {0, 0};   // bitmask of seeds already taken per strand (cnt0 <= 32)
-            for (u32 rank = 0; rank < cnt0 && !st.mapped; ++rank)
-            {
-                for (u32 strand = 0; strand < 2; ++strand)
-                {
-                    u32 best = 0xFFFFFFFFu, bestId = 0;
-                    for (u32 k = 0; k < cnt0; ++k)
-                    {
-                        if (done[strand] >> k & 1) continue;
-                        uint2 r = h0[strand * S0 + k];
-                        u32 c = r.y - r.x;
-                        if (c < best) { best = c; bestId = k; }
-                    }
-                    done[strand] |= 1u << bestId;
-                    uint2 r = h0[strand * S0 + bestId];
-                    extendRange<NW>(b, r.x, r.y, seedLen, strand ? seqRc : seq, len, strand, (cnt0 - 1 - bestId) * seedLen, readErrors, read, bin, st, sink);
-                }
-                if (st.minErrors + readStrata <= rank) st.mapped = true;     // seedErrors = 0: rank * (0 + 1)
-            }
-        }
-        return;
+        seq = rd.seqs + rd.offs[read];
+        seqRc = rd.seqsRc + rd.offs[read];
+        len = (u32)(rd.offs[read + 1] - rd.offs[read]);
+        readErrors = readErrorsOf(len, prm.errorRate); readStrata = readStrataOf(len, prm.strataRate);
+        b = makeBinView(ix, bin);
+        h0 = hits0 + (size_t)item * 2 * S0;
+        // ---- classifyReads (reference src/mapper_classifier.h:111-155)
+        cnt0 = seedCountOf(readErrors, 0);
+        u64 total = 0;
+        for (u32 s = 0; s < 2 * S0; ++s) total += h0[s].y - h0[s].x;
+        if (total > prm.hitsThreshold) seedErrors = (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
     }
+
+    // ---- rankSeeds + extendHits<0>(bucket 0) for the easy reads of the whole wavefront.
+    // Every lane walks its own (rank, strand, SA row) sequence — seeds by ascending hit count, ties keep ascending seed
+    // id, forward hits before reverse hits, early exit after a rank — but the lanes meet at ONE extension call per
+    // round, so the wavefront pays for max(#occurrences per lane) extensions instead of one per (rank, strand) pair.
+    {
+        bool active = valid && seedErrors == 0 && len >= cnt0;
+        const u32 seedLen = active ? len / cnt0 : 0;
+        u32 done[2] = {0, 0};   // bitmask of seeds already taken per strand (cnt0 <= 32)
+        u32 rank = 0, strand = 0, row = 0, rowEnd = 0, needleBegin = 0;
+        auto pickSeed = [&]() {
+            u32 best = 0xFFFFFFFFu, bestId = 0;
+            for (u32 k = 0; k < cnt0; ++k)
+            {
+                if (done[strand] >> k & 1) continue;
+                const uint2 r = h0[strand * S0 + k];
+                const u32 c = r.y - r.x;
+                if (c < best) { best = c; bestId = k; }
+            }
+            done[strand] |= 1u << bestId;
+            const uint2 r = h0[strand * S0 + bestId];
+            row = r.x; rowEnd = r.y; needleBegin = (cnt0 - 1 - bestId) * seedLen;
+        };
+        if (active) pickSeed();
+        for (;;)
+        {
+            bool have = false;
+            while (active)
+            {
+                if (row < rowEnd) { have = true; break; }
+                if (strand == 0) { strand = 1; pickSeed(); }
+                else
+                {
+                    if (st.minErrors + readStrata <= rank) { st.mapped = true; active = false; break; }   // seedErrors = 0: rank * (0 + 1)
+                    if (++rank >= cnt0) { active = false; break; }
+                    strand = 0; pickSeed();
+                }
+            }
+            if (!__ballot(have)) break;
+            if (have && !(sink.debugFlags & 2))
+            {   // _extendHitImpl for one SA row (reference src/mapper_extender.h:263-285)
+                u32 contig, x;
+                fmLocate(b, row, contig, x);
+                ++row;
+                const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+                if (clen - x >= seedLen && !(sink.debugFlags & 1))
+                    extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
+            }
+            else if (have) ++row;
+        }
+    }
+    if (!valid || seedErrors == 0) return;
 
     // ---- hard read: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2)
     atomicAdd(hardItems, 1u);
@@ -537,6 +564,40 @@ __global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, cons
             }
             if (st.minErrors + readStrata <= rank * (E + 1)) st.mapped = true;
         }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
+                                                u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
+                                                u32 * __restrict__ hardItems)
+{
+    const u32 item = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
+    ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
+    u32 read = 0;
+    u32 bin = 0;
+    const bool valid = item < nItems;
+    if (valid) { read = itemRead[item]; bin = itemBin[item]; }
+    extendItem<NW>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardItems, st, valid);
+    // one reservation per wavefront for the buffered matches
+    const u32 cnt = st.nbuf;
+    u32 incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+    const u32 total = __shfl(incl, 63, 64);
+    if (!total) return;
+    u32 base = 0;
+    if (lane == 63) base = atomicAdd(sink.poolCount, total);
+    base = __shfl(base, 63, 64);
+    const u32 first = base + incl - cnt;
+    if (cnt >= 1)
+    {
+        if (first < sink.poolCap) { sink.pool[first] = st.buf0; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+    if (cnt >= 2)
+    {
+        if (first + 1 < sink.poolCap) { sink.pool[first + 1] = st.buf1; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
     }
 }
 
