@@ -76,7 +76,7 @@ struct dy_ctx
     dy_map_stats stats = {};
     bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
-    DevBuf waveCounts, waveOffsets, complexList, alignList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
+    DevBuf waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp;
     size_t poolCap = 0;
 };
@@ -584,7 +584,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         ctx->dp.reserve(dpStride * finWaves + 64);
         FinalizeArgs fa;
         fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.nReads = nReads;
-        fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate;
+        fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
         fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
         fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
         fa.debugFlags = getenv("DY_DEBUG_FINALIZE") ? (u32)atoi(getenv("DY_DEBUG_FINALIZE")) : 0;
@@ -593,9 +593,12 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
         ctx->alignList.reserve((size_t)nReads * 4 + 64);
         u32 * alignCount = ctx->counters.as<u32>() + 4;
+        ctx->smallList.reserve((size_t)nReads * 4 + 64);
+        u32 * smallCount = ctx->counters.as<u32>() + 5;
         hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
-                           ctx->alignList.as<u32>(), alignCount);
+                           ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
         hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
+        hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
         hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
