@@ -358,11 +358,15 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         if (reads->n)
         {
             const u32 wavesPerBlock = 4;
-            size_t lds = (size_t)wavesPerBlock * 64 * W * sizeof(u16);
+            size_t lds = 0;
             HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-            hipLaunchKernelGGL(k_ibf_query, dim3((reads->n + wavesPerBlock - 1) / wavesPerBlock), dim3(64 * wavesPerBlock), lds, ctx->stream,
-                               f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(), reads->n, (u32)threshold,
-                               reads->masks.as<u64>());
+            const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+            if (reads->maxLen < 127 + f->g.kmerSize)
+                hipLaunchKernelGGL(k_ibf_query<7>, grid, block, lds, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                   reads->n, (u32)threshold, reads->masks.as<u64>());
+            else
+                hipLaunchKernelGGL(k_ibf_query<14>, grid, block, lds, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                   reads->n, (u32)threshold, reads->masks.as<u64>());
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
         }

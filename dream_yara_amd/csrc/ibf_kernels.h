@@ -55,103 +55,197 @@ __device__ __forceinline__ u32 strandCode(const u8 * __restrict__ seq, u32 len, 
     return (strand && c < 4) ? 3 - c : c;
 }
 
-// counts: LDS, one u16 per bin for this wave (64*W entries)
+// k-mer hash of lane `lane` in the chunk starting at k-mer `base` of one strand (SeqAn Shape<Dna,SimpleShape>)
+__device__ __forceinline__ u64 laneKmerHash(const u8 * __restrict__ seq, u32 len, u32 strand, u32 base, u32 lane, u32 k, u64 kMask, bool firstIsN)
+{
+    // bit planes of bases [base, base+128)
+    u32 c0 = strandCode(seq, len, base + lane, strand), c1 = strandCode(seq, len, base + 64 + lane, strand);
+    if (c0 > 3) c0 = 0;
+    if (c1 > 3) c1 = 0;
+    const u64 p0lo = ballot64(c0 & 1), p1lo = ballot64(c0 & 2), p0hi = ballot64(c1 & 1), p1hi = ballot64(c1 & 2);
+    // bits [lane, lane+k) of the 128-bit planes
+    u64 x0 = lane ? ((p0lo >> lane) | (p0hi << (64 - lane))) : p0lo;
+    u64 x1 = lane ? ((p1lo >> lane) | (p1hi << (64 - lane))) : p1lo;
+    x0 &= kMask; x1 &= kMask;
+    // base t of the k-mer carries weight 4^(k-1-t): reverse the k bits, then interleave the planes
+    const u64 r0 = __brevll(x0) >> (64 - k), r1 = __brevll(x1) >> (64 - k);
+    u64 hash = spreadBits(r0) | (spreadBits(r1) << 1);
+    const u32 i = base + lane;
+    if (firstIsN && 2 * (k + i) < 64) hash += 1ull << (2 * (k + i));
+    return hash;
+}
+
+// ---- bit-sliced per-bin counters: plane p holds bit p of the count of each of the 64 bins of one mask word ----
+// NP planes count up to 2^NP - 1 k-mers: 7 for reads up to ~140 bp, 14 for the 8191-bp maximum
+
+// Sum over the 64 lanes of a one-bit-per-bin mask: butterfly of ripple-carry adders, result replicated in every lane.
+__device__ __forceinline__ void waveBitSlicedSum(u64 m, u64 (&s)[7])
+{
+    s[0] = m;
+#pragma unroll
+    for (int p = 1; p < 7; ++p) s[p] = 0;
+#pragma unroll
+    for (int l = 0; l < 6; ++l)
+    {
+        const int d = 1 << l;
+        u64 carry = 0;
+#pragma unroll
+        for (int p = 0; p <= l; ++p)
+        {
+            const u64 o = ((u64)__shfl_xor((u32)(s[p] >> 32), d, 64) << 32) | __shfl_xor((u32)s[p], d, 64);
+            const u64 x = s[p] ^ o;
+            const u64 sum = x ^ carry;
+            carry = (s[p] & o) | (carry & x);
+            s[p] = sum;
+        }
+        s[l + 1] = carry;
+    }
+}
+// planes += s (s has 7 planes)
+template <int NP>
+__device__ __forceinline__ void planesAdd(u64 (&planes)[NP], const u64 (&s)[7])
+{
+    u64 carry = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+    {
+        const u64 b = p < 7 ? s[p] : 0;
+        const u64 x = planes[p] ^ b;
+        const u64 sum = x ^ carry;
+        carry = (planes[p] & b) | (carry & x);
+        planes[p] = sum;
+    }
+}
+// mask of bins whose count >= c
+template <int NP>
+__device__ __forceinline__ u64 planesGe(const u64 (&planes)[NP], int c)
+{
+    if (c <= 0) return ~0ull;
+    if (c >= (1 << NP)) return 0;
+    u64 gt = 0, eq = ~0ull;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p)
+    {
+        const u64 cb = ((c >> p) & 1) ? ~0ull : 0ull;
+        gt |= eq & planes[p] & ~cb;
+        eq &= ~(planes[p] ^ cb);
+    }
+    return gt | eq;
+}
+template <int NP>
+__device__ __forceinline__ u32 planesGet(const u64 (&planes)[NP], u32 j)
+{
+    u32 v = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v |= (u32)((planes[p] >> j) & 1) << p;
+    return v;
+}
+
+// K1.  The answer per bin is only "count >= threshold", so the sweep needs as few gathers as it takes to decide every bin
+// exactly (the gather rate, ~55 G/s on a 1 GiB table, is the hardware limit of this kernel):
+//   phase A  looks up hash function 0 only.  Its per-bin counts are upper bounds of the real counts (the AND over all
+//            hash functions can only clear bits), so a bin whose bound stays below the threshold is rejected for good;
+//            the phase stops as soon as no bin can reach the threshold any more.  Counts are bit-sliced: one wave-wide
+//            adder butterfly per 64 k-mers, no per-bin loop although every lane's word carries several bits.
+//   phase B  verifies the few surviving candidate bins (normally the read's own bin) with the remaining hash
+//            functions, 32 k-mers at a time, and stops per bin once count >= threshold or
+//            count + (unverified k-mers that carry the bin's bit in word 0) < threshold.
+// For a 100-bp read of one bin this is ~83 + ~70 + 64 gathers instead of 2*83*3.
+template <int NP>
 __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ words, IbfGeom g,
                                                    const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
                                                    u32 threshold, u64 * __restrict__ masks)
 {
-    extern __shared__ u16 ldsCounts[];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
     if (read >= nReads) return;
-    u16 * counts = ldsCounts + (size_t)wave * 64 * g.W;
     const u8 * seq = seqs + offs[read];
     const u32 len = (u32)(offs[read + 1] - offs[read]);
     const u32 k = g.kmerSize;
     u64 * out = masks + (size_t)read * g.W;
 
-    if (len < k)
-    {   // no k-mer: every count is 0
-        for (u32 w = lane; w < g.W; w += 64) out[w] = threshold == 0 ? ~0ull : 0ull;
+    if (len < k || threshold == 0)
+    {   // no k-mer: every count is 0; threshold 0 selects every bin (counts >= 0)
+        for (u32 w = lane; w < g.W; w += 64)
+        {
+            const u32 left = g.nBins - w * 64;
+            out[w] = threshold == 0 ? (left >= 64 ? ~0ull : ((1ull << left) - 1)) : 0ull;
+        }
         return;
     }
     const u32 nKmers = len - k + 1;
     const u64 kMask = (1ull << k) - 1;          // k <= 32 (checked at load/create)
 
-    u64 selOwn = 0;   // selected bins: lane l owns mask word l (W <= 64)
-
-    // Pruning that cannot change the result: once every bin is decided (count >= threshold, or count + remaining <
-    // threshold) the remaining k-mers are not looked up.  The last `tail` k-mers (at most threshold-2, so that a bin
-    // with a single stray hit is already decided) form their own chunk; for reads that really come from one bin this
-    // skips about a third of the gathers of both strands.
-    const u32 tail = threshold >= 2 ? min(min(threshold - 2, 64u), nKmers) : 0;
-    const u32 head = nKmers - tail;
-
-    for (u32 strand = 0; strand < 2; ++strand)
+    for (u32 w = 0; w < g.W; ++w)
     {
-        for (u32 b = lane; b < 64 * g.W; b += 64) counts[b] = 0;
-        const bool firstIsN = strandCode(seq, len, 0, strand) > 3;     // SeqAn hashInit takes text[0] uncast
-        u32 base = 0, limit = head;
-        for (u32 phase = 0; phase < 2; ++phase)
+        const u32 left = g.nBins - w * 64;
+        const u64 binMask = left >= 64 ? ~0ull : ((1ull << left) - 1);
+        u64 selW = 0;
+        for (u32 strand = 0; strand < 2; ++strand)
         {
-            if (phase == 1)
+            const bool firstIsN = strandCode(seq, len, 0, strand) > 3;     // SeqAn hashInit takes text[0] uncast
+            // ---- phase A: hash function 0, bit-sliced upper bounds
+            u64 planes[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) planes[p] = 0;
+            u64 cached0 = 0, cached1 = 0;       // word 0 of this lane's k-mer in chunks 0 and 1
+            bool alive = true;
+            for (u32 base = 0; base < nKmers && alive; base += 64)
             {
-                if (!tail) break;
-                bool undecided = false;
-                for (u32 w = 0; w < g.W; ++w)
-                {
-                    const u32 c = counts[w * 64 + lane];
-                    undecided |= __ballot(c < threshold && c + tail >= threshold) != 0;
-                }
-                if (!undecided) break;
-                base = head; limit = nKmers;
+                const u64 hash = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
+                const bool valid = base + lane < nKmers;
+                const u64 m = valid ? words[ibfWordIndex(g, hash, 0) + w] : 0;
+                if (base == 0) cached0 = m; else if (base == 64) cached1 = m;
+                u64 s[7];
+                waveBitSlicedSum(m, s);
+                planesAdd(planes, s);
+                const u32 remaining = nKmers - min(nKmers, base + 64);
+                if (remaining) alive = (planesGe(planes, (int)threshold - (int)remaining) & binMask) != 0;
             }
-            for (; base < limit; base += 64)
+            if (!alive) continue;               // no bin of this strand can reach the threshold
+            // ---- phase B: exact decision for the candidate bins
+            u64 und = planesGe(planes, (int)threshold) & binMask;
+            u32 exactCnt[4] = {0, 0, 0, 0}, seenCnt[4] = {0, 0, 0, 0};   // per candidate slot (first 4 candidates in registers)
+            // candidates beyond 4 are handled by re-running the loop (rare): process in groups of 4
+            while (und)
             {
-                // bit planes of bases [base, base+128)
-                u32 c0 = strandCode(seq, len, base + lane, strand), c1 = strandCode(seq, len, base + 64 + lane, strand);
-                if (c0 > 3) c0 = 0;
-                if (c1 > 3) c1 = 0;
-                const u64 p0lo = ballot64(c0 & 1), p1lo = ballot64(c0 & 2), p0hi = ballot64(c1 & 1), p1hi = ballot64(c1 & 2);
-                const u32 i = base + lane;
-                const bool valid = i < limit;
-                // bits [lane, lane+k) of the 128-bit planes
-                u64 x0 = lane ? ((p0lo >> lane) | (p0hi << (64 - lane))) : p0lo;
-                u64 x1 = lane ? ((p1lo >> lane) | (p1hi << (64 - lane))) : p1lo;
-                x0 &= kMask; x1 &= kMask;
-                // base t of the k-mer carries weight 4^(k-1-t): reverse the k bits, then interleave the planes
-                u64 r0 = __brevll(x0) >> (64 - k), r1 = __brevll(x1) >> (64 - k);
-                u64 hash = spreadBits(r0) | (spreadBits(r1) << 1);
-                if (firstIsN && 2 * (k + i) < 64) hash += 1ull << (2 * (k + i));
-
-                for (u32 w = 0; w < g.W; ++w)
+                u64 group = 0; u32 gbin[4]; u32 gn = 0;
+                { u64 t = und; while (t && gn < 4) { const u32 j = __ffsll((long long)t) - 1; t &= t - 1; gbin[gn++] = j; group |= 1ull << j; } }
+                und &= ~group;
+                u64 open = group;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { exactCnt[q] = 0; seenCnt[q] = 0; }
+                for (u32 base = 0; base < nKmers && open; base += 64)
                 {
-                    u64 m = 0;
-                    if (valid)
+                    const u64 hash = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
+                    const bool valid = base + lane < nKmers;
+                    u64 m0;
+                    if (base == 0) m0 = cached0;
+                    else if (base == 64) m0 = cached1;
+                    else m0 = valid ? words[ibfWordIndex(g, hash, 0) + w] : 0;
+                    for (u32 half = 0; half < 2 && open; ++half)
                     {
-                        m = ~0ull;
-                        for (u32 hf = 0; hf < g.nHashes; ++hf) m &= words[ibfWordIndex(g, hash, hf) + w];
-                    }
-                    u64 cand = waveOr64(m);
-                    while (cand)
-                    {
-                        u32 j = __ffsll((long long)cand) - 1;
-                        cand &= cand - 1;
-                        u32 cnt = __popcll(ballot64((m >> j) & 1));
-                        if (lane == 0) counts[w * 64 + j] += (u16)cnt;
+                        const bool act = valid && (lane >> 5) == half;
+                        u64 full = act ? m0 : 0;
+                        if (act && (m0 & open))
+                            for (u32 hf = 1; hf < g.nHashes; ++hf) full &= words[ibfWordIndex(g, hash, hf) + w];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            if ((u32)q >= gn) continue;
+                            const u32 j = gbin[q];
+                            if (!((open >> j) & 1)) continue;
+                            exactCnt[q] += (u32)__popcll(ballot64(act && ((full >> j) & 1)));
+                            seenCnt[q] += (u32)__popcll(ballot64(act && ((m0 >> j) & 1)));
+                            if (exactCnt[q] >= threshold) { selW |= 1ull << j; open &= ~(1ull << j); }
+                            else if (exactCnt[q] + (planesGet(planes, j) - seenCnt[q]) < threshold) open &= ~(1ull << j);
+                        }
                     }
                 }
             }
         }
-        // whichBins tail: selected[bin] |= counts[bin] >= threshold   (reference src/d_bloom_filter.h:219-223)
-        for (u32 w = 0; w < g.W; ++w)
-        {
-            u32 bin = w * 64 + lane;
-            u64 sel = ballot64(bin < g.nBins && counts[bin] >= threshold);
-            if (lane == (w & 63)) selOwn |= sel;     // W <= 64: word w lives in lane w
-        }
+        if (lane == 0) out[w] = selW;
     }
-    if (lane < g.W) out[lane] = selOwn;
 }
 
 // Insertion: thread per k-mer (reference src/d_bloom_filter.h:293-315). seq = Dna5 codes on the device.

@@ -55,8 +55,6 @@ int dyo_ibf_query(void * fv, const u8 * seqs, const u64 * offs, u32 n, u16 thres
             else if (threshold == 0) sel.assign(f.noOfBins, true);
             for (u32 w = 0; w < f.binIntWidth; ++w) masks[(size_t)i * f.binIntWidth + w] = 0;
             for (u32 b = 0; b < f.noOfBins; ++b) if (sel[b]) masks[(size_t)i * f.binIntWidth + b / 64] |= 1ull << (b % 64);
-            if (threshold == 0 && len < f.kmerSize)
-                for (u32 w = 0; w < f.binIntWidth; ++w) masks[(size_t)i * f.binIntWidth + w] = ~0ull;
         }
         return 0;
     }
