@@ -94,6 +94,7 @@ struct dy_reads
     dy_ctx * ctx = nullptr;
     u32 n = 0; u64 totalBases = 0; u32 maxLen = 0; u32 minLen = 0;
     DevBuf seqs, seqsRc, offs, masks;
+    std::vector<u32> lens;   // host copy of the read lengths (MAPQ needs them)
     u32 maskW = 0;       // words per read currently held in masks (0 = none)
     u32 maskBins = 0;
 };
@@ -328,6 +329,7 @@ int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, u
             u64 l = offs[i + 1] - offs[i];
             if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");      // reference src/mapper.h:453-454
             mx = std::max<u32>(mx, (u32)l); mn = std::min<u32>(mn, (u32)l);
+            r->lens.push_back((u32)l);
         }
         r->maxLen = mx; r->minLen = n_reads ? mn : 0;
         r->seqs.reserve(r->totalBases + 64);
@@ -607,12 +609,8 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
 
-        // read lengths for the host-side MAPQ
-        res->readLens.resize(nReads);
-        std::vector<u64> offs(nReads + 1);
-        HIP_CHECK(hipMemcpyAsync(offs.data(), reads->offs.p, (size_t)(nReads + 1) * 8, hipMemcpyDeviceToHost, st));
+        res->readLens = reads->lens;       // for the host-side MAPQ
         HIP_CHECK(hipStreamSynchronize(st));
-        for (u32 i = 0; i < nReads; ++i) res->readLens[i] = (u32)(offs[i + 1] - offs[i]);
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;

@@ -100,6 +100,10 @@ __device__ __forceinline__ void waveBitSlicedSum(u64 m, u64 (&s)[7])
         }
         s[l + 1] = carry;
     }
+    // every lane now holds the same totals: move them to scalar registers (the per-strand counters then live on the SALU)
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+        s[p] = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(s[p] >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)s[p]);
 }
 // planes += s (s has 7 planes)
 template <int NP>
@@ -205,16 +209,13 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
             if (!alive) continue;               // no bin of this strand can reach the threshold
             // ---- phase B: exact decision for the candidate bins
             u64 und = planesGe(planes, (int)threshold) & binMask;
-            u32 exactCnt[4] = {0, 0, 0, 0}, seenCnt[4] = {0, 0, 0, 0};   // per candidate slot (first 4 candidates in registers)
-            // candidates beyond 4 are handled by re-running the loop (rare): process in groups of 4
             while (und)
-            {
-                u64 group = 0; u32 gbin[4]; u32 gn = 0;
-                { u64 t = und; while (t && gn < 4) { const u32 j = __ffsll((long long)t) - 1; t &= t - 1; gbin[gn++] = j; group |= 1ull << j; } }
-                und &= ~group;
-                u64 open = group;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { exactCnt[q] = 0; seenCnt[q] = 0; }
+            {   // one candidate bin at a time (there is normally exactly one: the bin the read comes from)
+                const u32 j = __ffsll((long long)und) - 1;
+                und &= und - 1;
+                const u32 bound0 = planesGet(planes, j);
+                u32 exactCnt = 0, seenCnt = 0;
+                bool open = true;
                 for (u32 base = 0; base < nKmers && open; base += 64)
                 {
                     const u64 hash = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
@@ -223,23 +224,17 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
                     if (base == 0) m0 = cached0;
                     else if (base == 64) m0 = cached1;
                     else m0 = valid ? words[ibfWordIndex(g, hash, 0) + w] : 0;
+                    const bool has0 = valid && ((m0 >> j) & 1);
                     for (u32 half = 0; half < 2 && open; ++half)
                     {
-                        const bool act = valid && (lane >> 5) == half;
-                        u64 full = act ? m0 : 0;
-                        if (act && (m0 & open))
-                            for (u32 hf = 1; hf < g.nHashes; ++hf) full &= words[ibfWordIndex(g, hash, hf) + w];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                        {
-                            if ((u32)q >= gn) continue;
-                            const u32 j = gbin[q];
-                            if (!((open >> j) & 1)) continue;
-                            exactCnt[q] += (u32)__popcll(ballot64(act && ((full >> j) & 1)));
-                            seenCnt[q] += (u32)__popcll(ballot64(act && ((m0 >> j) & 1)));
-                            if (exactCnt[q] >= threshold) { selW |= 1ull << j; open &= ~(1ull << j); }
-                            else if (exactCnt[q] + (planesGet(planes, j) - seenCnt[q]) < threshold) open &= ~(1ull << j);
-                        }
+                        const bool act = has0 && (lane >> 5) == half;
+                        bool hit = act;
+                        if (act)
+                            for (u32 hf = 1; hf < g.nHashes; ++hf) hit &= (words[ibfWordIndex(g, hash, hf) + w] >> j) & 1;
+                        exactCnt += (u32)__popcll(ballot64(hit));
+                        seenCnt += (u32)__popcll(ballot64(act));
+                        if (exactCnt >= threshold) { selW |= 1ull << j; open = false; }
+                        else if (exactCnt + (bound0 - seenCnt) < threshold) open = false;
                     }
                 }
             }
