@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=60000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -172,6 +172,14 @@ def main():
         bytes_per_read = 2 * (wl["L"] - wl["k"] + 1) * wl["h"] * W * 8
         k1_s = stage_ms["ms_ibf"] / steps / 1e3
         achieved = bytes_per_read * wl["reads"] / k1_s / 1e9 if k1_s > 0 else 0.0
+        # HBM traffic of K1 per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
+        # narrow gathers are accounted at 64 B per request, calibrated on scripts/ubench_gather.hip: profiles/r01_fetch_size_calibration.json)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01e_pmc_config2.json")
+        if args.workload == "config2" and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file)).get("void dy::k_ibf_query<7>", {})
+            if "FETCH_SIZE" in pmc:
+                traffic = (pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
         out = {
             "metric": "mapped reads/sec (whole node), 100 bp SE, 64-bin IBF",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,8 +190,8 @@ def main():
                        "items_per_read": stats["items"] / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
                        "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
             "roofline": {"kernel": "k_ibf_query", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "note": "algorithmic bytes %d B/read x %d reads per launch; each 8 B word costs a 64 B HBM fetch at W=1 (hardware bytes = 8x)" % (bytes_per_read, wl["reads"])},
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "note": "algorithmic bytes %d B/read x %d reads per launch; every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result" % (bytes_per_read, wl["reads"])},
         }
         if args.cpu_sample > 0 and world == 1:
             fpath = os.path.join(work_dir, "bench.filter")
