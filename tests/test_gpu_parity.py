@@ -118,6 +118,39 @@ def test_ibf_edge_cases(dy, ctx, ob, tmp_path, bins, hashes, k, bits):
     dreads.close(); ibf.close(); oibf.close()
 
 
+def test_ibf_beyond_4gib_matches_oracle(dy, ctx, ob, tmp_path):
+    """256 bins (W = 4) over a 5 GiB filter: word indices no longer fit 32 bits.  Filter built on the device, saved in
+    the reference's file format, re-read by the oracle; masks must agree for reads sampled from the bins."""
+    rng = np.random.default_rng(41)
+    bins, k, h = 256, 18, 3
+    bits = 5 * (1 << 33)
+    genomes = [rng.integers(0, 4, 20000, dtype=np.uint8) for _ in range(bins)]
+    f = dy.Ibf.create(ctx, bins, h, k, bits + 256)
+    for b, g in enumerate(genomes):
+        f.add(g, b)
+    path = str(tmp_path / "big.filter")
+    f.save(path)
+    reads = []
+    for i in range(3000):
+        b = int(rng.integers(0, bins)); s = int(rng.integers(0, 20000 - 100))
+        r = genomes[b][s:s + 100].copy()
+        for _ in range(int(rng.integers(0, 4))):
+            q = int(rng.integers(0, 100)); r[q] = (r[q] + 1) & 3
+        if i % 2: r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    codes = np.concatenate(reads); offs = np.arange(len(reads) + 1, dtype=np.uint64) * np.uint64(100)
+    dreads = dy.Reads(ctx, codes, offs)
+    thr = dy.threshold(np.float32(0.03), k, 100)
+    got = f.query(dreads, thr)
+    oibf = ob.OracleIbf(path)
+    assert (oibf.n_bins, oibf.W, oibf.n_hash_pos) == (bins, 4, bits // 256)
+    want = oibf.query(codes, offs, thr)
+    assert np.array_equal(got, want)
+    assert got.any(axis=1).all()          # every read selects at least its own bin
+    dreads.close(); f.close(); oibf.close()
+    os.remove(path)
+
+
 def test_ibf_built_on_gpu_equals_oracle_file(dy, ctx, ob, tmp_path):
     _, codes, offs = read_fasta_codes(GENOMES_FA)
     a, b = str(tmp_path / "gpu.filter"), str(tmp_path / "cpu.filter")
