@@ -29,7 +29,8 @@ class IbfInfo(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("error_rate", C.c_float), ("strata_rate", C.c_float), ("sensitivity", C.c_uint32),
-                ("hits_threshold", C.c_uint32), ("use_filter", C.c_uint32), ("reserved", C.c_uint32)]
+                ("hits_threshold", C.c_uint32), ("use_filter", C.c_uint32), ("paired", C.c_uint32), ("library_length", C.c_uint32),
+                ("library_dev", C.c_uint32), ("verify_matches", C.c_uint32), ("indel_rate", C.c_float)]
 
 
 class Match(C.Structure):
@@ -39,7 +40,8 @@ class Match(C.Structure):
 
 class ReadResult(C.Structure):
     _fields_ = [("primary", Match), ("mapped", C.c_uint32), ("best_count", C.c_uint32), ("sub_count", C.c_uint32),
-                ("mapq", C.c_uint32), ("set_begin", C.c_uint32), ("cigar_begin", C.c_uint32), ("cigar_len", C.c_uint32)]
+                ("mapq", C.c_uint32), ("set_begin", C.c_uint32), ("cigar_begin", C.c_uint32), ("cigar_len", C.c_uint32),
+                ("paired", C.c_uint32), ("reserved", C.c_uint32), ("pair_prob", C.c_double)]
 
 
 class MapStats(C.Structure):
@@ -50,7 +52,8 @@ class MapStats(C.Structure):
 
 MATCH_DTYPE = np.dtype([("contig", "<u4"), ("begin", "<u4"), ("length", "<u2"), ("errors", "u1"), ("is_rev", "u1")])
 READ_RESULT_DTYPE = np.dtype([("primary", MATCH_DTYPE), ("mapped", "<u4"), ("best_count", "<u4"), ("sub_count", "<u4"),
-                              ("mapq", "<u4"), ("set_begin", "<u4"), ("cigar_begin", "<u4"), ("cigar_len", "<u4")])
+                              ("mapq", "<u4"), ("set_begin", "<u4"), ("cigar_begin", "<u4"), ("cigar_len", "<u4"),
+                              ("paired", "<u4"), ("reserved", "<u4"), ("pair_prob", "<f8")])
 
 # every symbol include/dyhip.h declares: (name, restype, argtypes)
 _P = C.c_void_p

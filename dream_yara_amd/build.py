@@ -26,7 +26,7 @@ def _newer(target, sources):
 
 
 def _sources():
-    out = [os.path.join(ROOT, "include", "dyhip.h")]
+    out = [os.path.join(ROOT, "include", "dyhip.h"), os.path.abspath(__file__)]
     for f in sorted(os.listdir(CSRC)):
         if f.endswith((".h", ".hpp", ".hip", ".cpp")):
             out.append(os.path.join(CSRC, f))
@@ -40,9 +40,9 @@ def _run(cmd):
 
 def build(force=False):
     srcs = _sources()
-    lib_srcs = [s for s in srcs if not s.endswith(".cpp")]
+    lib_srcs = [s for s in srcs if not s.endswith(".cpp")]   # headers, .hip and this build script
     if force or not _newer(LIB, lib_srcs):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB,
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB,
               os.path.join(CSRC, "dyhip.hip")])
     for tool in ("dream_yara_mapper", "dream_yara_build_filter", "dream_yara_indexer"):
         src = os.path.join(CSRC, tool + ".cpp")

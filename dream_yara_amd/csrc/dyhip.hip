@@ -15,6 +15,7 @@
 #include "ibf_kernels.h"
 #include "map_kernels.h"
 #include "finalize_kernels.h"
+#include "pe_kernels.h"
 
 using namespace dy;
 
@@ -76,7 +77,8 @@ struct dy_ctx
     dy_map_stats stats = {};
     bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
-    DevBuf waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
+    DevBuf peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
+           waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp;
     size_t poolCap = 0;
 };
@@ -124,7 +126,7 @@ struct dy_index
 struct dy_result
 {
     dy_ctx * ctx = nullptr;
-    u32 nReads = 0; u32 nPool = 0; u32 cigarStride = 0;
+    u32 nReads = 0; u32 nPool = 0; u32 cigarStride = 0; size_t setCap = 0;
     std::vector<u32> readLens;
     DevBuf out, outSet, cigars;
     bool fetched = false;
@@ -462,7 +464,8 @@ void dy_index_free(dy_index * idx) { if (idx) { (void)hipSetDevice(idx->ctx->dev
 void dy_params_default(dy_params * p)
 {
     if (!p) return;
-    p->error_rate = 0.05f; p->strata_rate = 0.0f; p->sensitivity = 1; p->hits_threshold = 300; p->use_filter = 1; p->reserved = 0;
+    p->error_rate = 0.05f; p->strata_rate = 0.0f; p->sensitivity = 1; p->hits_threshold = 300; p->use_filter = 1;
+    p->paired = 0; p->library_length = 0; p->library_dev = 0; p->verify_matches = 1; p->indel_rate = 0.25f;
 }
 
 int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, dy_result ** out)
@@ -488,9 +491,16 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         }
         else if (reads->maskW != W || reads->maskBins != nBins)
             throw DyError(DY_EINVAL, "dy_ibf_query must run on these reads first (with a filter of the index's bin count)");
+        const bool paired = p->paired != 0;
+        if (paired && (nReads & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
+        if (paired && nReads)
+            hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(nReads / 2) * W + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nReads / 2, W);
 
         std::unique_ptr<dy_result> res(new dy_result);
-        res->ctx = ctx; res->nReads = nReads; res->cigarStride = 2 * maxErr + 1;
+        // a rescued mate may carry up to maxErrors + maxIndels 'errors' (score / -999, reference src/find_verifier.h:112-139)
+        u32 maxMatchErr = maxErr;
+        if (p->paired && p->verify_matches) { u32 mi = (u32)((float)reads->maxLen * p->indel_rate); maxMatchErr = std::min<u32>(MAX_ERRORS, maxErr + std::min<u32>(mi, MAX_ERRORS)); }
+        res->ctx = ctx; res->nReads = nReads; res->cigarStride = 2 * maxMatchErr + 1;
         res->out.reserve((size_t)nReads * sizeof(ReadOut) + 64);
         res->cigars.reserve((size_t)nReads * res->cigarStride * 4 + 64);
         ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
@@ -582,11 +592,13 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
             hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, ctx->pool.as<RawMatch>(), nPool, ctx->readStart.as<u32>(),
                                ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>());
         ctx->aux.reserve((size_t)nPool * 16 + 64);
-        ctx->marr.reserve((size_t)nPool * 3 * sizeof(RawMatch) + 64);
-        ctx->maux.reserve((size_t)nPool * 6 * 4 + 64);
-        res->outSet.reserve((size_t)nPool * 3 * sizeof(OutMatch) + 64);
+        const size_t setCap = paired ? (size_t)nPool * 3 + nItems : (size_t)nPool * 3;
+        res->setCap = setCap;
+        ctx->marr.reserve(setCap * sizeof(RawMatch) + 64);
+        ctx->maux.reserve(setCap * 2 * 4 + 64);
+        res->outSet.reserve(setCap * sizeof(OutMatch) + 64);
         const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
-        const size_t dpStride = (dpScratchBytes(reads->maxLen, maxErr) + 15) & ~(size_t)15;
+        const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
         ctx->dp.reserve(dpStride * finWaves + 64);
         FinalizeArgs fa;
         fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.nReads = nReads;
@@ -597,15 +609,66 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         ctx->complexList.reserve((size_t)nReads * 4 + 64);
         u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
         fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
-        ctx->alignList.reserve((size_t)nReads * 4 + 64);
-        u32 * alignCount = ctx->counters.as<u32>() + 4;
-        ctx->smallList.reserve((size_t)nReads * 4 + 64);
-        u32 * smallCount = ctx->counters.as<u32>() + 5;
-        hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
-                           ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
-        hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
-        hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
-        hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
+        if (!paired)
+        {
+            ctx->alignList.reserve((size_t)nReads * 4 + 64);
+            u32 * alignCount = ctx->counters.as<u32>() + 4;
+            ctx->smallList.reserve((size_t)nReads * 4 + 64);
+            u32 * smallCount = ctx->counters.as<u32>() + 5;
+            hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
+                               ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
+            hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
+            hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
+            hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
+        }
+        else
+        {
+            // ---- paired-end stages (pe_kernels.h)
+            ctx->peItems.reserve((size_t)nItems * sizeof(PeItem) + 64);
+            ctx->peU2.reserve((size_t)nPool * sizeof(RawMatch) + 64);
+            ctx->peLib.reserve((size_t)nBins * sizeof(PeLibrary) + 64);
+            ctx->peLens.reserve((size_t)nItems * 4 + 64); ctx->peIdx.reserve((size_t)nItems * 4 + 64);
+            ctx->peHasRescue.reserve((size_t)nReads * 4 + 64); ctx->peJobs.reserve((size_t)nItems * 4 + 64);
+            HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
+            HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
+            PeView V;
+            V.items = ctx->peItems.as<PeItem>(); V.u2 = ctx->peU2.as<RawMatch>(); V.itemRead = ctx->itemRead.as<u32>(); V.itemBin = ctx->itemBin.as<u16>();
+            V.binStart = ctx->binStart.as<u32>(); V.masks = reads->masks.as<u64>(); V.W = W; V.nBins = nBins; V.nPairs = nReads / 2; V.nItems = nItems;
+            V.lib = ctx->peLib.as<PeLibrary>(); V.libLens = ctx->peLens.as<u32>(); V.libIdx = ctx->peIdx.as<u32>();
+            V.optLibLength = p->library_length; V.optLibDev = p->library_dev; V.verify = p->verify_matches;
+            V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
+            hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V);
+            hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(64), 0, st, V);
+            if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
+            if (p->verify_matches && nItems)
+            {
+                std::vector<PeLibrary> hostLib(nBins);
+                HIP_CHECK(hipMemcpyAsync(hostLib.data(), ctx->peLib.p, (size_t)nBins * sizeof(PeLibrary), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                u32 maxWindow = 0;
+                for (auto & l : hostLib) maxWindow = std::max(maxWindow, 6 * l.dev);
+                if (maxWindow)
+                {
+                    u32 * jobCount = ctx->counters.as<u32>() + 6;
+                    hipLaunchKernelGGL(k_pe_rescue_jobs, dim3((nItems + 255) / 256), dim3(256), 0, st, V, ctx->peJobs.as<u32>(), jobCount);
+                    const u32 rescueBlocks = 512, rescueWaves = rescueBlocks * 4;
+                    const size_t stride = (peRescueScratchBytes(reads->maxLen, maxWindow) + 63) & ~(size_t)63;
+                    ctx->peScratch.reserve(stride * rescueWaves + 64);
+                    hipLaunchKernelGGL(k_pe_rescue, dim3(rescueBlocks), dim3(256), 0, st, fa, V, ctx->peJobs.as<u32>(), jobCount, ctx->peScratch.as<u8>(), stride, maxWindow);
+                }
+            }
+            // room per read in the main mapper's match array: 3 per raw match + one per selected bin (a rescued mate)
+            ctx->peMCounts.reserve((size_t)(nReads + 1) * 4 + 64); ctx->peMStart.reserve((size_t)(nReads + 1) * 4 + 64);
+            hipLaunchKernelGGL(k_pe_mcounts, dim3((nReads + 1 + 255) / 256), dim3(256), 0, st, ctx->readMatchCount.as<u32>(), reads->masks.as<u64>(), W, nReads, ctx->peMCounts.as<u32>());
+            {
+                size_t tb = 0;
+                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
+                ctx->scanTmp.reserve(tb + 64);
+                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
+            }
+            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->complexList.as<u32>(), complexCount);
+            hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
+        }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
 
@@ -628,7 +691,7 @@ int dy_result_fetch(dy_result * r)
         dy_ctx * ctx = r->ctx;
         HIP_CHECK(hipSetDevice(ctx->device));
         std::vector<ReadOut> ro(r->nReads);
-        std::vector<OutMatch> os((size_t)r->nPool * 3);
+        std::vector<OutMatch> os(r->setCap);
         std::vector<u32> cg((size_t)r->nReads * r->cigarStride);
         if (r->nReads) HIP_CHECK(hipMemcpyAsync(ro.data(), r->out.p, ro.size() * sizeof(ReadOut), hipMemcpyDeviceToHost, ctx->stream));
         if (!os.empty()) HIP_CHECK(hipMemcpyAsync(os.data(), r->outSet.p, os.size() * sizeof(OutMatch), hipMemcpyDeviceToHost, ctx->stream));
@@ -642,7 +705,9 @@ int dy_result_fetch(dy_result * r)
             dy_read_result & d = r->reads[i];
             d.primary.contig = o.contig; d.primary.begin = o.begin; d.primary.length = o.length; d.primary.errors = o.errors; d.primary.is_rev = o.isRev;
             d.mapped = o.mapped; d.best_count = o.bestCount; d.sub_count = o.subCount;
-            d.mapq = o.mapped ? mapqOf(o.errors, r->readLens[i], o.bestCount, o.subCount) : 0;
+            d.paired = o.paired; d.reserved = 0; d.pair_prob = o.pairProb;
+            d.mapq = !o.mapped ? 0 : o.paired ? (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(o.pairProb, 0.9999999)))
+                                              : mapqOf(o.errors, r->readLens[i], o.bestCount, o.subCount);
             d.set_begin = (u32)r->matches.size();
             u32 nset = o.bestCount + o.subCount;
             for (u32 k = 0; k < nset; ++k)

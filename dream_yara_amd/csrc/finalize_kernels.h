@@ -19,7 +19,16 @@ struct ReadOut            // device mirror of dy_read_result (mapq filled on the
     u32 contig, begin;    // primary: global contig id, begin
     u16 length; u8 errors; u8 isRev;
     u32 mapped, bestCount, subCount, mapq, setBegin, cigarBegin, cigarLen;
+    u32 paired, reserved;   // paired-end: ReadsContext::paired of the main mapper
+    double pairProb;        // paired-end: primaryMatchesProbs[read]
 };
+
+__device__ __forceinline__ void initReadOut(ReadOut & ro, u32 setBegin, u32 cigarBegin)
+{
+    ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
+    ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = setBegin; ro.cigarBegin = cigarBegin; ro.cigarLen = 0;
+    ro.paired = 0; ro.reserved = 0; ro.pairProb = 0.0;
+}
 
 struct OutMatch { u32 contig; u32 begin; u16 length; u8 errors; u8 isRev; };
 
@@ -489,8 +498,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
         const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
         const u8 * seq = A.readSeqs + A.readOffs[read];
-        ReadOut ro; ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
-        ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
+        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
         if (n == 0) { if (lane == 0) A.out[read] = ro; continue; }
         const bool small = n <= SMALL_N;
         const u32 wv = threadIdx.x >> 6;
@@ -711,8 +719,7 @@ __global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList
     if (read >= A.nReads) return;
     const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
     const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
-    ReadOut ro; ro.contig = 0; ro.begin = 0; ro.length = 0; ro.errors = MAX_ERRORS; ro.isRev = 0;
-    ro.mapped = 0; ro.bestCount = 0; ro.subCount = 0; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
+    ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
     if (n == 0) { A.out[read] = ro; return; }
     if (n == 1)
     {
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(256) void k_align_single(FinalizeArgs A, const u32 
         const u32 read = alignList[li];
         const u32 s0 = A.readStart[read];
         const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
-        ReadOut ro; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride;
+        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
         RawMatch a = A.gp[s0];
         const BinDesc & bd = A.bins[a.bin];
         const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(256) void k_finalize_small(FinalizeArgs A, const u3
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
         const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
         const u8 * seq = A.readSeqs + A.readOffs[read];
-        ReadOut ro; ro.mapq = 0; ro.setBegin = 3 * s0; ro.cigarBegin = read * A.cigarStride; ro.cigarLen = 0;
+        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
         RawMatch E[SMALL_T], M[3 * SMALL_T];
         u32 idxA[SMALL_T], idxB[SMALL_T], idxM[3 * SMALL_T], idxF[3 * SMALL_T];
         for (u32 i = 0; i < n; ++i) { E[i] = A.gp[s0 + i]; idxA[i] = i; }

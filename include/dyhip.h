@@ -106,7 +106,11 @@ typedef struct {
     uint32_t sensitivity;     /* 0 low, 1 high (2 = full/edit-distance seeds: DY_EUNSUPPORTED) (:72,103) */
     uint32_t hits_threshold;  /* Options::hitsThreshold (:84,111), default 300 */
     uint32_t use_filter;      /* 0 = -ft none: every read goes to every bin (reference src/d_mapper.h:399-405) */
-    uint32_t reserved;
+    uint32_t paired;          /* 1 = paired-end: reads [0,n/2) are the first mates, [n/2,n) the second mates (reference src/bits_reads.h) */
+    uint32_t library_length;  /* Options::libraryLength, 0 = estimate per bin (reference src/mapper.h:76,929-985) */
+    uint32_t library_dev;     /* Options::libraryDev,    0 = estimate per bin */
+    uint32_t verify_matches;  /* Options::verifyMatches: mate rescue unless --no-indels (reference src/d_mapper.cpp:359) */
+    float    indel_rate;      /* Options::indelRate (reference src/mapper.h:69,100), default 0.25 */
 } dy_params;
 void dy_params_default(dy_params *p);
 
@@ -129,6 +133,9 @@ typedef struct {
     uint32_t set_begin;     /* [set_begin, set_begin+best_count+sub_count) in dy_result_matches(): matchesSet[read] */
     uint32_t cigar_begin;   /* [cigar_begin, cigar_begin+cigar_len) in dy_result_cigars() */
     uint32_t cigar_len;
+    uint32_t paired;        /* paired-end: ReadsContext::paired of the main mapper (reference src/d_mapper.h:202-206) */
+    uint32_t reserved;
+    double   pair_prob;     /* paired-end: primaryMatchesProbs[read]; mapq already uses it when paired */
 } dy_read_result;
 
 /* runDisMapper's per-batch body — reference src/d_mapper.h:874-886: for every bin selected by the masks left on

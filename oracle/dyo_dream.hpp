@@ -6,6 +6,7 @@
 //   SAM records                                              reference src/mapper_writer.h:124-215,221-225,296-345,593-634
 #pragma once
 #include "dyo_mapper.hpp"
+#include "dyo_detmath.hpp"
 #include <ostream>
 #include <sstream>
 #include <thread>
@@ -81,6 +82,8 @@ struct ReadResult
     std::vector<Match> matches;      // matchesSet[readId]: within strata, sorted by (errors, contig, strand, begin)
     u32 bestCount = 0, subCount = 0;
     std::vector<CigarOp> cigar;
+    bool paired = false;             // paired-end only: ReadsContext::paired of the main mapper
+    double pairProb = 0.0;           // paired-end only: primaryMatchesProbs[read]
 };
 
 struct DreamStats { u64 filteredReads = 0; BinMapStats bin; std::vector<u64> readsPerBin; };
@@ -234,6 +237,386 @@ public:
             res[i].cigar = collectedCigars[i];
         }
         return res;
+    }
+
+    // =====================================================================================================
+    // Paired-end (reference src/mapper.h:927-1172, src/bits_matches.h:816-1041, src/mapper_verifier.h, src/find_verifier.h,
+    // src/d_mapper.h:186-215,394-443).  UNPINNED: the reference ships no paired-end gold.
+    // Batch layout like the reference: reads [0,P) are the first mates, [P,2P) the second mates.
+    // =====================================================================================================
+    static bool orientationProper(const Match & one, const Match & two)
+    {
+        bool oneBeforeTwo = one.contigBegin < two.contigBegin;
+        return (!one.isRev && two.isRev && oneBeforeTwo) || (!two.isRev && one.isRev && !oneBeforeTwo);
+    }
+    static u32 libraryLengthOf(const Match & a, const Match & b)
+    {
+        if (a.valid() && b.valid() && a.contigId == b.contigId)
+            return (u32)(b.contigEnd() > a.contigBegin ? b.contigEnd() - a.contigBegin : a.contigEnd() - b.contigBegin);
+        return 0xFFFFFFFFu;
+    }
+    static u32 libraryDeviationOf(const Match & a, const Match & b, unsigned mean)
+    {
+        if (a.valid() && b.valid() && a.contigId == b.contigId)
+        {
+            int d = (int)libraryLengthOf(a, b) - (int)mean;
+            return (u32)(d < 0 ? -d : d);
+        }
+        return 0xFFFFFFFFu;
+    }
+    static double peResidualWeight(double errorRate) { double p = detPow10(std::min(2.0, 100.0 * errorRate - 7.0)); return p / (1.0 - p); }
+    static double peMatchWeight(double errorRate, double optimalRate) { return (1.0 - errorRate) / detPow10(300.0 * (errorRate - optimalRate)); }
+    static double peMatchProb(double errorRate, double optimalRate, u64 optimalCount, u64 subCount)
+    {
+        double w = optimalCount * peMatchWeight(optimalRate, optimalRate) + subCount * peMatchWeight(optimalRate + 0.01, optimalRate) + peResidualWeight(optimalRate);
+        return peMatchWeight(errorRate, optimalRate) / w;
+    }
+    static double libraryProbOf(const Match & one, const Match & two, unsigned mean, unsigned stdDev)
+    {
+        bool proper = orientationProper(one, two) && libraryDeviationOf(one, two, mean) < 6 * stdDev;
+        if (!proper) return 0.0009;
+        double dev = (double)libraryDeviationOf(one, two, mean);
+        double score = dev / stdDev;
+        return std::max(0.001, detErfc(score / 1.41421356237));
+    }
+
+    // findProperMates (src/bits_matches.h:819-867): [first,last) into `mates` (sorted by coordinate)
+    std::pair<size_t, size_t> findProperMates(const std::vector<Match> & mates, const Match & match, unsigned mateLength, u64 contigLength,
+                                              unsigned mean, unsigned stdDev) const
+    {
+        Match leq = match; leq.isRev = !match.isRev; Match geq = leq;
+        leq.errors = 0; geq.errors = MAX_MATCH_ERRORS;
+        int ml = (int)mateLength;
+        unsigned deltaMinus = (unsigned)std::max(0, (int)mean - (int)(6 * stdDev) - ml);
+        unsigned deltaPlus = (unsigned)std::max(0, (int)mean + (int)(6 * stdDev) - ml);
+        auto addPos = [&](Match & m, unsigned delta) { m.contigBegin = (m.contigBegin + m.contigLen + delta < contigLength) ? m.contigBegin + delta : contigLength - m.contigLen; };
+        auto subPos = [&](Match & m, unsigned delta) { m.contigBegin = m.contigBegin > delta ? m.contigBegin - delta : 0; };
+        if (!match.isRev) { addPos(leq, deltaMinus); addPos(geq, deltaPlus); }
+        else { subPos(leq, deltaPlus); subPos(geq, deltaMinus); }
+        auto keyB = [](const Match & a, const Match & b) {
+            if (a.contigId != b.contigId) return a.contigId < b.contigId;
+            if (a.isRev != b.isRev) return a.isRev < b.isRev;
+            if (a.contigBegin != b.contigBegin) return a.contigBegin < b.contigBegin;
+            return a.errors < b.errors; };
+        auto keyE = [](const Match & a, const Match & b) {
+            if (a.contigId != b.contigId) return a.contigId < b.contigId;
+            if (a.isRev != b.isRev) return a.isRev < b.isRev;
+            if (a.contigEnd() != b.contigEnd()) return a.contigEnd() < b.contigEnd();
+            return a.errors < b.errors; };
+        size_t first = std::lower_bound(mates.begin(), mates.end(), leq, keyB) - mates.begin();
+        size_t last = std::upper_bound(mates.begin(), mates.end(), geq, keyE) - mates.begin();
+        if (first > last) return {0, 0};
+        return {first, last};
+    }
+
+    // findPrimaryMatch (src/bits_matches.h:972-1041): index into firstMatches (or npos) and its probability
+    std::pair<size_t, double> findPrimaryMatch(const std::vector<Match> & firstMatches, const std::vector<Match> & secondMatches,
+                                               double firstOptimalRate, double secondOptimalRate, u64 secondOptimalCount, u64 secondSubCount,
+                                               unsigned firstLen, unsigned secondLen, u64 contigLengthOf(const void *, u32), const void * cl,
+                                               unsigned mean, unsigned stdDev) const
+    {
+        double sum = 0, best = 0; size_t bestIdx = (size_t)-1;
+        for (size_t i = 0; i < firstMatches.size(); ++i)
+        {
+            const Match & fm = firstMatches[i];
+            double w = 0;
+            u64 optImproper = secondOptimalCount, subImproper = secondSubCount;
+            auto range = findProperMates(secondMatches, fm, secondLen, contigLengthOf(cl, fm.contigId), mean, stdDev);
+            for (size_t k = range.first; k < range.second; ++k)
+            {
+                const Match & sm = secondMatches[k];
+                double secondErrorRate = (double)((float)sm.errors / (float)secondLen);
+                w += peMatchWeight(secondErrorRate, secondOptimalRate) * libraryProbOf(fm, sm, mean, stdDev);
+                if (secondErrorRate == secondOptimalRate) --optImproper;
+                else if (secondErrorRate == secondOptimalRate + 0.01) --subImproper;
+            }
+            w += ((double)optImproper * peMatchWeight(secondOptimalRate, secondOptimalRate) +
+                  (double)subImproper * peMatchWeight(secondOptimalRate + 0.01, secondOptimalRate) + peResidualWeight(secondOptimalRate)) * 0.0009;
+            double firstErrorRate = (double)((float)fm.errors / (float)firstLen);
+            w *= peMatchWeight(firstErrorRate, firstOptimalRate);
+            if (w > best) { best = w; bestIdx = i; }
+            sum += w;
+        }
+        return {bestIdx, best / sum};
+    }
+
+    static u64 contigLenThunk(const void * p, u32 c) { return ((const Bin *)p)->contigs.length(c); }
+
+    std::vector<ReadResult> mapBatchPaired(const ReadBatch & reads, DreamStats * stats = nullptr) const
+    {
+        const size_t n = reads.size(), P = n / 2;
+        const u32 numBins = (u32)idx.bins.size();
+        // clasifyLoadedReads for pairs: the four sequences of a pair vote together (src/d_mapper.h:350-358)
+        std::vector<std::vector<u32> > pairMap(numBins);
+        if (!opt.useFilter || !filter)
+            for (u32 b = 0; b < numBins; ++b) { pairMap[b].resize(P); std::iota(pairMap[b].begin(), pairMap[b].end(), 0u); }
+        else
+        {
+            u64 lengthSum = 0;
+            for (size_t i = 0; i < n; ++i) lengthSum += 2 * reads.fwd[i].size();
+            u16 avg = (u16)(lengthSum / (n * 2));
+            u16 thr = getThreshold(opt, filter->kmerSize, avg);
+            for (size_t p = 0; p < P; ++p)
+            {
+                std::vector<bool> sel(numBins, thr == 0);
+                if (thr)
+                    for (size_t r : {p, p + P})
+                    {
+                        if (reads.fwd[r].size() < filter->kmerSize) continue;
+                        ibfWhichBins(*filter, sel, reads.fwd[r].data(), reads.fwd[r].size(), thr);
+                        ibfWhichBins(*filter, sel, reads.rev[r].data(), reads.rev[r].size(), thr);
+                    }
+                for (u32 b = 0; b < numBins; ++b) if (sel[b]) pairMap[b].push_back((u32)p);
+            }
+        }
+        if (stats) { stats->readsPerBin.assign(numBins, 0); for (u32 b = 0; b < numBins; ++b) { stats->readsPerBin[b] = 2 * pairMap[b].size(); stats->filteredReads += 2 * pairMap[b].size(); } }
+        std::vector<u32> order(numBins);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return pairMap[a].size() > pairMap[b].size(); });
+
+        std::vector<std::vector<Match> > mainMatches(n);
+        std::vector<u8> mainMinErrors(n, 255);
+        std::vector<std::vector<CigarOp> > collectedCigars(n);
+        std::vector<bool> mainPaired(n, false);
+        std::vector<double> mainProbs(n, 0.0);
+
+        for (u32 binNo : order)
+        {
+            const std::vector<u32> & pids = pairMap[binNo];
+            const size_t Pc = pids.size();
+            if (!Pc) continue;
+            const Bin & bin = idx.bins[binNo];
+            auto origOf = [&](size_t r) { return r < Pc ? (size_t)pids[r] : (size_t)pids[r - Pc] + P; };
+            struct Child { std::vector<Match> all; size_t nu = 0; std::vector<size_t> byErr; size_t nOpt = 0, nSet = 0; size_t primary = (size_t)-1;
+                           bool mapped = false, paired = false; double prob = 0; bool rescued = false; Match mate; std::vector<CigarOp> cigar; };
+            std::vector<Child> ch(2 * Pc);
+            ReadBinMapper mapper(bin, opt);
+            BinMapStats bst;
+            for (size_t r = 0; r < 2 * Pc; ++r)
+            {
+                size_t orig = origOf(r);
+                unsigned L = (unsigned)reads.fwd[orig].size();
+                const u8 * seqs[2] = {reads.fwd[orig].data(), reads.rev[orig].data()};
+                Child & c = ch[r];
+                mapper.map(seqs, L, (u32)orig, c.all, stats ? &bst : nullptr);
+                if (c.all.empty()) continue;
+                c.nu = removeDuplicates(c.all);
+                c.byErr.resize(c.nu); std::iota(c.byErr.begin(), c.byErr.end(), (size_t)0);
+                std::stable_sort(c.byErr.begin(), c.byErr.end(), [&](size_t a, size_t b) { return c.all[a].errors < c.all[b].errors; });
+                unsigned strata = getReadStrata(opt, L);
+                while (c.nOpt < c.nu && c.all[c.byErr[c.nOpt]].errors <= c.all[c.byErr[0]].errors) ++c.nOpt;
+                while (c.nSet < c.nu && c.all[c.byErr[c.nSet]].errors <= c.all[c.byErr[0]].errors + strata) ++c.nSet;
+                c.primary = c.byErr[(size_t)libcxxFirstUniform(c.nOpt)];
+                c.mapped = true;
+            }
+            if (stats) { stats->bin.seeds += bst.seeds; stats->bin.hits += bst.hits; stats->bin.located += bst.located; stats->bin.extended += bst.extended; stats->bin.matches += bst.matches; }
+            // ---- library mean / deviation from unique proper pairs (src/mapper.h:929-985)
+            unsigned libraryLength = 0, libraryDev = 0;
+            bool pairing = true;
+            if (!opt.libraryLength || !opt.libraryDev)
+            {
+                std::vector<unsigned> lens;
+                for (size_t j = 0; j < Pc; ++j)
+                {
+                    const Child & a = ch[j], & b = ch[j + Pc];
+                    if (a.nOpt == 1 && b.nOpt == 1)
+                    {
+                        const Match & fm = a.all[a.byErr[0]], & sm = b.all[b.byErr[0]];
+                        if (fm.contigId == sm.contigId && orientationProper(fm, sm)) lens.push_back(libraryLengthOf(fm, sm));
+                    }
+                }
+                if (lens.empty()) pairing = false;
+                else
+                {
+                    std::vector<unsigned> tmp(lens);
+                    std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+                    unsigned median = tmp[tmp.size() / 2];
+                    std::vector<unsigned> kept;
+                    for (unsigned v : lens) if (!((double)v > 6.0 * median)) kept.push_back(v);
+                    if (kept.empty()) pairing = false;
+                    else
+                    {
+                        unsigned sum = 0; for (unsigned v : kept) sum += v;
+                        float mean = std::max(sum / static_cast<float>(kept.size()), 1.0f);
+                        float sq = 0.0f;
+                        for (unsigned v : kept) { float d = (float)v - mean; sq += d * d; }
+                        float dev = std::max(std::sqrt(sq / static_cast<float>(kept.size())), 1.0f);
+                        libraryLength = (unsigned)mean; libraryDev = (unsigned)dev;
+                    }
+                }
+            }
+            if (pairing)
+            {
+                if (opt.libraryLength) libraryLength = opt.libraryLength;
+                if (opt.libraryDev) libraryDev = opt.libraryDev;
+                // ---- enumerate feasible pairs (src/mapper.h:989-1061)
+                for (size_t j = 0; j < Pc; ++j)
+                {
+                    Child & a = ch[j], & b = ch[j + Pc];
+                    if (!a.nu || !b.nu) continue;
+                    std::vector<Match> am(a.all.begin(), a.all.begin() + a.nu), bm(b.all.begin(), b.all.begin() + b.nu);
+                    unsigned aLen = (unsigned)reads.fwd[origOf(j)].size(), bLen = (unsigned)reads.fwd[origOf(j + Pc)].size();
+                    double aOpt = (double)((float)a.all[a.byErr[0]].errors / (float)aLen), bOpt = (double)((float)b.all[b.byErr[0]].errors / (float)bLen);
+                    auto fa = findPrimaryMatch(am, bm, aOpt, bOpt, b.nOpt, b.nSet - b.nOpt, aLen, bLen, contigLenThunk, &bin, libraryLength, libraryDev);
+                    auto fb = findPrimaryMatch(bm, am, bOpt, aOpt, a.nOpt, a.nSet - a.nOpt, bLen, aLen, contigLenThunk, &bin, libraryLength, libraryDev);
+                    if (fa.first == (size_t)-1 || fb.first == (size_t)-1) continue;
+                    a.primary = fa.first; b.primary = fb.first;
+                    a.prob = fa.second; b.prob = fb.second;
+                    a.paired = b.paired = true;
+                }
+            }
+            // ---- verifyMatches: rescue the unmapped mate of a uniquely anchored read (src/mapper_verifier.h:141-273)
+            if (opt.verifyMatches)
+            {
+                for (size_t r = 0; r < 2 * Pc; ++r)
+                {
+                    Child & anchorC = ch[r];
+                    size_t mr = r < Pc ? r + Pc : r - Pc;
+                    Child & mateC = ch[mr];
+                    if (anchorC.nOpt != 1 || mateC.mapped) continue;
+                    const Match & anchor = anchorC.all[anchorC.byErr[0]];
+                    size_t mateOrig = origOf(mr);
+                    bool mateRev = !anchor.isRev;                      // getMateSeqId: the mate is searched on the opposite strand
+                    const std::vector<u8> & mateSeq = mateRev ? reads.rev[mateOrig] : reads.fwd[mateOrig];
+                    u64 contigLength = bin.contigs.length(anchor.contigId);
+                    u64 wb = 0, we = 0;
+                    if (mateRev)
+                    {   // --> ... mate
+                        if (anchor.contigBegin + libraryLength > 3ull * libraryDev) wb = anchor.contigBegin + libraryLength - 3ull * libraryDev;
+                        wb = std::min(wb, contigLength);
+                        we = std::min<u64>(anchor.contigBegin + libraryLength + 3ull * libraryDev, contigLength);
+                    }
+                    else
+                    {   // mate ... <--
+                        if (anchor.contigEnd() > (u64)libraryLength + 3ull * libraryDev) wb = anchor.contigEnd() - libraryLength - 3ull * libraryDev;
+                        if (anchor.contigEnd() + libraryDev > libraryLength) we = anchor.contigEnd() - libraryLength + 3ull * libraryDev;
+                        we = std::min(we, contigLength);
+                    }
+                    if (we <= wb) continue;
+                    int mb, me, errs;
+                    unsigned L = (unsigned)mateSeq.size();
+                    if (!verifyMate(bin.contigs.seq(anchor.contigId) + wb, (int)(we - wb), mateSeq.data(), (int)L, getReadErrors(opt, L), getReadIndels(opt, L), mb, me, errs))
+                        continue;
+                    mateC.rescued = true;
+                    mateC.mate.readId = (u32)mateOrig; mateC.mate.contigId = anchor.contigId; mateC.mate.isRev = mateRev;
+                    mateC.mate.contigBegin = wb + (u64)mb; mateC.mate.contigLen = (u32)(me - mb); mateC.mate.errors = (u32)errs;
+                }
+                for (size_t mr = 0; mr < 2 * Pc; ++mr)
+                {
+                    Child & mateC = ch[mr];
+                    if (!mateC.rescued) continue;
+                    Child & anchorC = ch[mr < Pc ? mr + Pc : mr - Pc];
+                    mateC.mapped = true; mateC.paired = true; anchorC.paired = true;
+                    const Match & ap = anchorC.all[anchorC.primary];
+                    unsigned aLen = (unsigned)reads.fwd[origOf(mr < Pc ? mr + Pc : mr - Pc)].size();
+                    double rate = (double)((float)ap.errors / (float)aLen);
+                    anchorC.prob = peMatchProb(rate, rate, anchorC.nOpt, anchorC.nSet - anchorC.nOpt);
+                    mateC.prob = anchorC.prob;
+                }
+            }
+            // ---- alignMatches + copyMatches + copyCigars
+            u32 coff = idx.contigOffsets[binNo];
+            for (size_t r = 0; r < 2 * Pc; ++r)
+            {
+                Child & c = ch[r];
+                size_t orig = origOf(r);
+                unsigned L = (unsigned)reads.fwd[orig].size();
+                Match * pm = nullptr;
+                if (c.rescued) pm = &c.mate;
+                else if (c.mapped) pm = &c.all[c.primary];
+                if (pm)
+                {
+                    const u8 * rs = pm->isRev ? reads.rev[orig].data() : reads.fwd[orig].data();
+                    int cb, ce;
+                    c.cigar = alignMatch(bin.contigs.seq(pm->contigId) + pm->contigBegin, (int)pm->contigLen, rs, (int)L, (int)pm->errors, cb, ce);
+                    if (!(pm->errors == 0 || (pm->errors == 1 && pm->contigLen == L))) { pm->contigBegin += (u64)cb; pm->contigLen = (u32)ce; }
+                }
+                for (Match m : c.all) { m.contigId += coff; m.readId = (u32)orig; mainMatches[orig].push_back(m); }
+                if (c.rescued) { Match m = c.mate; m.contigId += coff; mainMatches[orig].push_back(m); }
+                if (pm)
+                {
+                    if (pm->errors < mainMinErrors[orig]) mainMinErrors[orig] = (u8)pm->errors;
+                    if (!mainPaired[orig] && c.paired) { mainPaired[orig] = true; mainProbs[orig] = c.prob; }
+                    if (mainMinErrors[orig] == pm->errors) collectedCigars[orig] = c.cigar;
+                }
+            }
+        }
+        std::vector<ReadResult> res(n);
+        for (size_t i = 0; i < n; ++i)
+        {
+            std::vector<Match> & all = mainMatches[i];
+            size_t nu = removeDuplicates(all);
+            std::vector<Match> uniq(all.begin(), all.begin() + nu);
+            rankRead(uniq, getReadStrata(opt, (unsigned)reads.fwd[i].size()), res[i]);
+            res[i].cigar = collectedCigars[i];
+            res[i].paired = mainPaired[i]; res[i].pairProb = mainProbs[i];
+        }
+        return res;
+    }
+
+    // SAM records of a paired batch (src/mapper_writer.h:268-293,347-400,515-571); reads [0,P) first mates, [P,2P) second mates
+    void writeRecordsPaired(std::ostream & os, const ReadBatch & reads, const std::vector<ReadResult> & res) const
+    {
+        const size_t n = reads.size(), P = n / 2;
+        for (size_t i = 0; i < n; ++i)
+        {
+            const ReadResult & r = res[i];
+            const size_t mate = i < P ? i + P : i - P;
+            const ReadResult & mr = res[mate];
+            std::string qname = reads.names[i];
+            size_t cut = qname.find_first_of(" \t/");
+            if (cut != std::string::npos) qname.resize(cut);
+            bool rev = r.mapped && r.primary.isRev;
+            const std::vector<u8> & s = rev ? reads.rev[i] : reads.fwd[i];
+            std::string seq(s.size(), 'N'), qual(reads.qual[i]);
+            for (size_t k = 0; k < s.size(); ++k) seq[k] = DNA5_CHARS[s[k]];
+            if (rev) std::reverse(qual.begin(), qual.end());
+            unsigned flag = 1 | (i < P ? 64 : 128);
+            if (!mr.mapped) flag |= 8;
+            std::string rname = "*", rnext = "*"; u64 pos = 0, pnext = 0; long long tlen = 0; unsigned mapq = 0; std::string cigar = "*";
+            if (!r.mapped)
+            {
+                flag |= 4;
+                if (mr.mapped)
+                {
+                    rname = idx.contigNames[mr.primary.contigId]; pos = mr.primary.contigBegin + 1;
+                    rnext = "="; pnext = mr.primary.contigBegin + 1;
+                    if (mr.primary.isRev) flag |= 32;
+                }
+                os << qname << "\t" << flag << "\t" << rname << "\t" << pos << "\t0\t*\t" << rnext << "\t" << pnext << "\t0\t" << seq << "\t" << qual
+                   << "\tRG:Z:" << opt.readGroup << "\n";
+                continue;
+            }
+            if (rev) flag |= 16;
+            rname = idx.contigNames[r.primary.contigId]; pos = r.primary.contigBegin + 1; cigar = cigarToString(r.cigar);
+            if (mr.mapped)
+            {
+                rnext = mr.primary.contigId == r.primary.contigId ? "=" : idx.contigNames[mr.primary.contigId];
+                pnext = mr.primary.contigBegin + 1;
+                if (mr.primary.isRev) flag |= 32;
+                if (r.paired)
+                {
+                    if (orientationProper(r.primary, mr.primary)) flag |= 2;
+                    if (r.primary.contigId == mr.primary.contigId)
+                        tlen = r.primary.contigBegin < mr.primary.contigBegin ? (long long)mr.primary.contigEnd() - (long long)r.primary.contigBegin
+                                                                                : (long long)mr.primary.contigBegin - (long long)r.primary.contigEnd();
+                }
+            }
+            else { rnext = "="; pnext = r.primary.contigBegin + 1; }
+            if (r.paired) mapq = getMapq(r.pairProb);
+            else { double errorRate = (double)((float)r.primary.errors / (float)s.size()); mapq = getMapq(getMatchProb(errorRate, errorRate, r.bestCount, r.subCount)); }
+            os << qname << "\t" << flag << "\t" << rname << "\t" << pos << "\t" << mapq << "\t" << cigar << "\t" << rnext << "\t" << pnext << "\t" << tlen
+               << "\t" << seq << "\t" << qual << "\tNM:i:" << r.primary.errors << "\tX0:i:" << r.bestCount << "\tX1:i:" << r.subCount << "\tRG:Z:" << opt.readGroup;
+            std::string xa; bool skipped = false;
+            for (const Match & m : r.matches)
+            {
+                if (!skipped && dupBegin(m, r.primary)) { skipped = true; continue; }
+                xa += idx.contigNames[m.contigId]; xa += ','; xa += std::to_string(m.contigBegin + 1); xa += ',';
+                xa += std::to_string(m.contigEnd() + 1); xa += ','; xa += m.isRev ? '-' : '+'; xa += ','; xa += std::to_string(m.errors); xa += ';';
+            }
+            if (!xa.empty()) os << "\tXA:Z:" << xa;
+            os << "\n";
+        }
     }
 
     // ---- SAM ----

@@ -34,6 +34,9 @@ struct Options
     unsigned readsCount = 100000;
     unsigned threads = 1;
     bool     useFilter = true;
+    float    indelRate = 0.25f;
+    unsigned libraryLength = 0, libraryDev = 0;
+    bool     verifyMatches = true;
     std::string readGroup = "none";
     std::string version = "1.0.2 []";
     std::string commandLine;
@@ -51,6 +54,11 @@ inline unsigned getReadStrata(const Options & o, unsigned readLen)
 {
     unsigned s = o.strataCount != 0xFFFFFFFFull ? (unsigned)o.strataCount : (unsigned)(readLen * o.strataRate);
     return std::min<unsigned>(s, MAX_MATCH_ERRORS);
+}
+// reference src/misc_options.h:270-275
+inline unsigned getReadIndels(const Options & o, unsigned readLen)
+{
+    return std::min<unsigned>((unsigned)(readLen * o.indelRate), MAX_MATCH_ERRORS);
 }
 // reference src/d_mapper.h:83-92
 inline u16 getThreshold(const Options & o, u32 kmerSize, u16 readLen)
@@ -584,6 +592,72 @@ inline std::vector<CigarOp> alignMatch(const u8 * contig, int n, const u8 * read
     clipBegin = j; clipEnd = bj;
     for (auto it = ops.rbegin(); it != ops.rend(); ++it) push(*it);
     return cigar;
+}
+
+// ----------------------------------------------------------------------------
+// Mate rescue (reference src/find_verifier.h:80-140): UNBANDED semi-global affine alignment of the mate against the
+// insert window (contig horizontal, free leading/trailing contig gaps), same scores and tie-breaks as alignMatch.
+// On success returns true with the clipped window-relative [begin,end) and errors = score / -999.
+// ----------------------------------------------------------------------------
+inline bool verifyMate(const u8 * window, int n, const u8 * read, int m, unsigned maxErrors, unsigned maxIndels,
+                       int & matchBegin, int & matchEnd, int & errorsOut)
+{
+    if (n <= 0) return false;
+    const int NEG = -(1 << 28), MISMATCH = -1000, GEXT = -999, GOPEN = -1001;
+    std::vector<int> S((size_t)(m + 1) * (n + 1), NEG), H(S), V(S);
+    std::vector<u8> trS(S.size(), 0), trH(S.size(), 0), trV(S.size(), 0);
+    auto at = [&](int i, int j) { return (size_t)i * (n + 1) + j; };
+    enum { DIAG = 1, HOR = 2, VER = 3 };
+    for (int j = 0; j <= n; ++j) S[at(0, j)] = 0;
+    for (int i = 1; i <= m; ++i)
+        for (int j = 0; j <= n; ++j)
+        {
+            size_t c = at(i, j);
+            {
+                int ext = V[at(i - 1, j)] + GEXT, opn = S[at(i - 1, j)] + GOPEN;
+                if (ext >= opn) { V[c] = ext; trV[c] = 1; } else { V[c] = opn; trV[c] = 0; }
+            }
+            if (j > 0)
+            {
+                int ext = H[at(i, j - 1)] + GEXT, opn = S[at(i, j - 1)] + GOPEN;
+                if (ext >= opn) { H[c] = ext; trH[c] = 1; } else { H[c] = opn; trH[c] = 0; }
+            }
+            int best = NEG; u8 tb = 0;
+            if (j > 0) { best = S[at(i - 1, j - 1)] + (dnaEq(window[j - 1], read[i - 1]) ? 0 : MISMATCH); tb = DIAG; }
+            if (V[c] > best) { best = V[c]; tb = VER; }
+            if (H[c] > best) { best = H[c]; tb = HOR; }
+            S[c] = best; trS[c] = tb;
+        }
+    int bj = -1, bs = NEG;
+    for (int j = 0; j <= n; ++j) if (S[at(m, j)] > bs) { bs = S[at(m, j)]; bj = j; }
+    int i = m, j = bj, state = 0;
+    unsigned gapOpens = 0, gapChars = 0;
+    int lastOp = -1;
+    while (i > 0)
+    {
+        size_t c = at(i, j);
+        int op;
+        if (state == 0)
+        {
+            if (trS[c] == DIAG) { op = 0; --i; --j; }
+            else if (trS[c] == VER) { state = 1; continue; }
+            else if (trS[c] == HOR) { state = 2; continue; }
+            else break;
+        }
+        else if (state == 1) { op = 1; bool ext = trV[c]; --i; if (!ext) state = 0; }
+        else { op = 2; bool ext = trH[c]; --j; if (!ext) state = 0; }
+        if (op != 0) { ++gapChars; if (op != lastOp) ++gapOpens; }
+        lastOp = op;
+    }
+    int errors = bs / -999;
+    unsigned gapExtensions = gapChars - gapOpens;
+    unsigned events = (unsigned)errors + gapOpens - gapExtensions;
+    if (events <= maxErrors && gapChars <= maxIndels)
+    {
+        matchBegin = j; matchEnd = bj; errorsOut = errors;
+        return true;
+    }
+    return false;
 }
 
 } // namespace dyo

@@ -6,7 +6,8 @@ using namespace dyo;
 
 namespace {
 struct OMatch { u32 contig; u32 begin; u16 length; u8 errors; u8 is_rev; };
-struct ORead { OMatch primary; u32 mapped, best_count, sub_count, mapq, set_begin, cigar_begin, cigar_len; };
+struct ORead { OMatch primary; u32 mapped, best_count, sub_count, mapq, set_begin, cigar_begin, cigar_len, paired, reserved; double pair_prob; };
+static_assert(sizeof(ORead) == 56, "layout must match the numpy dtype");
 struct OResult { std::vector<ORead> reads; std::vector<OMatch> matches; std::vector<u32> cigars; DreamStats stats; };
 thread_local std::string g_err;
 OMatch conv(const Match & m) { OMatch o; o.contig = m.contigId; o.begin = (u32)m.contigBegin; o.length = (u16)m.contigLen; o.errors = (u8)m.errors; o.is_rev = m.isRev; return o; }
@@ -98,18 +99,19 @@ int dyo_index_build(const char * prefix, const u8 * seqs, const u64 * offs, u32 
     catch (std::exception const & e) { g_err = e.what(); return -1; }
 }
 
-void * dyo_map_batch(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
-                     unsigned hitsThreshold, unsigned threads)
+static void * mapBatchImpl(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
+                           unsigned hitsThreshold, unsigned threads, bool paired, unsigned libraryLength, unsigned libraryDev, int verify)
 {
     try
     {
         DreamIndex & idx = *(DreamIndex *)idxv;
         Options opt; opt.errorRate = errorRate; opt.strataRate = strataRate; opt.sensitivity = sensitivity; opt.hitsThreshold = hitsThreshold;
         opt.threads = threads; opt.useFilter = ibfv != nullptr;
+        opt.libraryLength = libraryLength; opt.libraryDev = libraryDev; opt.verifyMatches = verify != 0;
         ReadBatch batch = makeBatch(seqs, offs, n);
         DreamMapper mapper(idx, (IBF *)ibfv, opt);
         OResult * R = new OResult;
-        std::vector<ReadResult> res = mapper.mapBatch(batch, &R->stats);
+        std::vector<ReadResult> res = paired ? mapper.mapBatchPaired(batch, &R->stats) : mapper.mapBatch(batch, &R->stats);
         R->reads.resize(n);
         for (u32 i = 0; i < n; ++i)
         {
@@ -119,11 +121,12 @@ void * dyo_map_batch(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs
             o.mapped = r.mapped; o.best_count = r.mapped ? r.bestCount : 0; o.sub_count = r.mapped ? r.subCount : 0;
             o.primary.errors = 127;
             o.set_begin = (u32)R->matches.size(); o.cigar_begin = (u32)R->cigars.size();
+            o.paired = r.paired; o.pair_prob = r.pairProb;
             if (r.mapped)
             {
                 o.primary = conv(r.primary);
                 double rate = (double)((float)r.primary.errors / (float)batch.fwd[i].size());
-                o.mapq = getMapq(getMatchProb(rate, rate, r.bestCount, r.subCount));
+                o.mapq = r.paired ? getMapq(r.pairProb) : getMapq(getMatchProb(rate, rate, r.bestCount, r.subCount));
                 for (auto & m : r.matches) R->matches.push_back(conv(m));
                 for (auto & c : r.cigar) R->cigars.push_back((c.count << 4) | (c.op == 'M' ? 0u : c.op == 'I' ? 1u : 2u));
                 o.cigar_len = (u32)r.cigar.size();
@@ -132,6 +135,17 @@ void * dyo_map_batch(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs
         return R;
     }
     catch (std::exception const & e) { g_err = e.what(); return nullptr; }
+}
+void * dyo_map_batch(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
+                     unsigned hitsThreshold, unsigned threads)
+{
+    return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, threads, false, 0, 0, 1);
+}
+// paired-end: reads [0,n/2) are the first mates, [n/2,n) the second mates
+void * dyo_map_batch_paired(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
+                            unsigned hitsThreshold, unsigned libraryLength, unsigned libraryDev, int verify)
+{
+    return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, 1, true, libraryLength, libraryDev, verify);
 }
 void dyo_result_free(void * r) { delete (OResult *)r; }
 u64 dyo_result_n_matches(void * r) { return ((OResult *)r)->matches.size(); }

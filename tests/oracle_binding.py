@@ -9,7 +9,8 @@ LIB = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 
 MATCH_DTYPE = np.dtype([("contig", "<u4"), ("begin", "<u4"), ("length", "<u2"), ("errors", "u1"), ("is_rev", "u1")])
 READ_RESULT_DTYPE = np.dtype([("primary", MATCH_DTYPE), ("mapped", "<u4"), ("best_count", "<u4"), ("sub_count", "<u4"),
-                              ("mapq", "<u4"), ("set_begin", "<u4"), ("cigar_begin", "<u4"), ("cigar_len", "<u4")])
+                              ("mapq", "<u4"), ("set_begin", "<u4"), ("cigar_begin", "<u4"), ("cigar_len", "<u4"),
+                              ("paired", "<u4"), ("reserved", "<u4"), ("pair_prob", "<f8")])
 
 _lib = None
 
@@ -31,6 +32,8 @@ def lib():
         l.dyo_index_build.restype = C.c_int; l.dyo_index_build.argtypes = [C.c_char_p, P, P, C.c_uint32]
         l.dyo_map_batch.restype = P
         l.dyo_map_batch.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint]
+        l.dyo_map_batch_paired.restype = P
+        l.dyo_map_batch_paired.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int]
         l.dyo_result_free.argtypes = [P]
         l.dyo_result_n_matches.restype = C.c_uint64; l.dyo_result_n_matches.argtypes = [P]
         l.dyo_result_n_cigars.restype = C.c_uint64; l.dyo_result_n_cigars.argtypes = [P]
@@ -94,13 +97,20 @@ class OracleIndex:
             self.h = None
 
 
-def map_batch(index, ibf, codes, offs, error_rate, strata_rate=0.0, sensitivity=1, hits_threshold=300, threads=4):
-    """Returns (reads, matches, cigars, stats) as numpy arrays laid out like the device results."""
+def map_batch(index, ibf, codes, offs, error_rate, strata_rate=0.0, sensitivity=1, hits_threshold=300, threads=4,
+              paired=False, library_length=0, library_dev=0, verify=True):
+    """Returns (reads, matches, cigars, stats) as numpy arrays laid out like the device results.
+    paired=True: reads [0,n/2) are the first mates, [n/2,n) the second mates."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = offs.size - 1
-    h = lib().dyo_map_batch(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
-                            np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold, threads)
+    if paired:
+        h = lib().dyo_map_batch_paired(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
+                                       np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold,
+                                       library_length, library_dev, 1 if verify else 0)
+    else:
+        h = lib().dyo_map_batch(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
+                                np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold, threads)
     if not h:
         raise _err()
     try:

@@ -322,6 +322,86 @@ def test_empty_batch_and_unmappable_reads(dy, ctx, ob, tmp_path):
     res.close(); r.close(); idx.close()
 
 
+# ---------------------------------------------------------------------------------------------- paired-end (unpinned: oracle only)
+def _make_pairs(rng, genomes, n_pairs, L, mean=300, sd=25):
+    r1, r2 = [], []
+    for i in range(n_pairs):
+        b = int(rng.integers(0, len(genomes))); g = genomes[b]
+        ins = max(L + 10, int(rng.normal(mean, sd))); s = int(rng.integers(0, g.size - ins - 12))
+        a = g[s:s + L].copy()
+        tmpl = g[s + ins - L - 8:s + ins].copy()
+        def mutate(r, k):
+            for _ in range(k):
+                q = int(rng.integers(0, r.size)); r[q] = (r[q] + 1 + int(rng.integers(0, 3))) & 3
+        kind = i % 10
+        if kind == 0:      # long deletion in the mate: seeds + extension fail, the rescue DP finds it
+            cut = int(rng.integers(3, 6)); q = int(rng.integers(20, L - 20))
+            tmpl = np.concatenate([tmpl[:q], tmpl[q + cut:]])
+        elif kind == 1:    # long insertion
+            add = int(rng.integers(3, 6)); q = int(rng.integers(20, L - 20))
+            tmpl = np.concatenate([tmpl[:q], rng.integers(0, 4, add, dtype=np.uint8), tmpl[q:]])
+        elif kind == 2:    # hopeless mate
+            tmpl = rng.integers(0, 4, L + 8, dtype=np.uint8)
+        m = tmpl[-L:] if kind != 2 else tmpl[:L]
+        m = (3 - m[::-1]).astype(np.uint8)
+        mutate(a, int(rng.integers(0, 3))); mutate(m, int(rng.integers(0, 2)))
+        if i % 2: a, m = m, a
+        r1.append(a.astype(np.uint8)); r2.append(m.astype(np.uint8))
+    reads = r1 + r2
+    codes = np.concatenate(reads)
+    offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    return codes, offs
+
+
+@pytest.mark.parametrize("use_filter,ll,ld,verify,strata", [(False, 0, 0, True, 0), (True, 0, 0, True, 2), (True, 320, 30, True, 0), (False, 0, 0, False, 0)])
+def test_paired_end_matches_oracle(dy, ctx, ob, tmp_path, use_filter, ll, ld, verify, strata):
+    rng = np.random.default_rng(77 + ll + strata)
+    n_bins = 5
+    genomes = [rng.integers(0, 4, 50000, dtype=np.uint8) for _ in range(n_bins)]
+    genomes[1][3000:3400] = genomes[1][9000:9400]          # a repeat: several co-optimal pairs
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    fpath = None
+    if use_filter:
+        fpath = str(tmp_path / "f.filter")
+        goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+        ob.build_filter(fpath, n_bins, 3, 16, 1 << 24, np.concatenate(genomes), goffs)
+    codes, offs = _make_pairs(rng, genomes, 1200, 100)
+    er, sr = np.float32(0.03), np.float32(strata / 100.0)
+    idx = dy.Index(ctx, idx_dir, n_bins)
+    reads = dy.Reads(ctx, codes, offs)
+    params = dy.default_params(error_rate=er, strata_rate=sr, paired=1, library_length=ll, library_dev=ld, verify_matches=1 if verify else 0)
+    ibf = None
+    if fpath:
+        ibf = dy.Ibf.load(ctx, fpath)
+        ibf.query(reads, dy.threshold(er, 16, 100), want_masks=False)
+    else:
+        params.use_filter = 0
+    res = dy.map_reads(ctx, idx, reads, params)
+    dev = (res.reads(), res.matches(), res.cigars())
+    stats = ctx.stats()
+    res.close(); reads.close(); idx.close()
+    if ibf: ibf.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins)
+    oibf = ob.OracleIbf(fpath) if fpath else None
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er, sr, paired=True, library_length=ll, library_dev=ld, verify=verify)
+    assert stats["items"] == ostats["items"]
+    assert stats["raw_matches"] == ostats["raw_matches"]
+    assert np.array_equal(dev[0]["paired"], o_reads["paired"])
+    assert np.array_equal(dev[0]["pair_prob"], o_reads["pair_prob"])          # bit-identical doubles (dy_detmath.h)
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
+    se_reads = ob.map_batch(oidx, oibf, codes, offs, er, sr)[0]
+    rescued = int(o_reads["mapped"].sum()) - int(se_reads["mapped"].sum())
+    assert o_reads["paired"].sum() > 1500
+    if verify:
+        assert rescued > 10, rescued           # the long-indel mates are only reachable through the rescue DP
+    else:
+        assert rescued == 0
+    oidx.close()
+    if oibf: oibf.close()
+
+
 # ---------------------------------------------------------------------------------------------- larger sizes: properties
 def test_error_free_reads_map_to_their_origin_at_scale(dy, ctx, product_build, tmp_path):
     from dream_yara_amd import synth
