@@ -8,6 +8,7 @@
 #include <sstream>
 #include <algorithm>
 #include <chrono>
+#include <memory>
 
 using namespace dy;
 
@@ -15,7 +16,7 @@ namespace {
 
 struct CliOptions
 {
-    std::string indicesDir, readsFile, outputFile, filterFile, filterType = "bloom", readGroup = "none";
+    std::string indicesDir, readsFile, readsFile2, outputFile, filterFile, filterType = "bloom", readGroup = "none";
     dy_params params;
     unsigned readsBatch = 100000;
     bool verbose = false, skipSamHeader = false;
@@ -61,13 +62,18 @@ CliOptions parse(int argc, char ** argv)
         else if (a == "-t" || a == "--threads") uintValue(1, 2048);      // the device replaces the thread pool
         else if (a == "-rb" || a == "--reads-batch") o.readsBatch = uintValue(1000, 5000000);
         else if (a == "-sk" || a == "--skip-sam-headers") o.skipSamHeader = true;
+        else if (a == "-ll" || a == "--library-length") o.params.library_length = uintValue(1, 1000000000u);      // src/d_mapper.cpp:209-216
+        else if (a == "-ld" || a == "--library-deviation") o.params.library_dev = uintValue(1, 1000000000u);
+        else if (a == "-i" || a == "--indel-rate") o.params.indel_rate = (float)(uintValue(0, 50) / 100.0);         // :355-357
+        else if (a == "-ni" || a == "--no-indels") o.params.verify_matches = 0;                                      // :359
         else if (a == "-v" || a == "--verbose" || a == "-vv" || a == "--very-verbose") o.verbose = true;
         else if (a.size() > 1 && a[0] == '-') fail("unknown option " + a);
         else pos.push_back(a);
     }
     if (pos.size() < 2) fail("usage: dream_yara_mapper [OPTIONS] <INDEX DIR> <READS>");
-    if (pos.size() > 2) fail("paired-end mapping is not implemented (DY_EUNSUPPORTED)");
+    if (pos.size() > 3) fail("Too many arguments!");                                                              // :300-302
     o.indicesDir = pos[0]; o.readsFile = pos[1];
+    if (pos.size() == 3) { o.readsFile2 = pos[2]; o.params.paired = 1; }
     if (o.indicesDir.empty() || o.indicesDir.back() != '/') o.indicesDir += '/';                                // appendTrailingSlash :280
     if (o.filterFile.empty()) o.filterFile = o.indicesDir + "bloom.filter";                                     // :371-375
     if (o.readsBatch > 2097151) o.readsBatch = 2097151;
@@ -117,12 +123,26 @@ int main(int argc, char ** argv)
         }
 
         ReadsFile in(opt.readsFile);
+        std::unique_ptr<ReadsFile> in2;
+        if (opt.params.paired) in2.reset(new ReadsFile(opt.readsFile2));
+        if (opt.params.paired && opt.readsBatch > 1048575) opt.readsBatch = 1048575;      // both mates share the 21-bit read id space
         ReadsBatch batch;
         unsigned long long total = 0, mapped = 0;
         double mapSeconds = 0;
         std::string rec;
         while (in.next(batch, opt.readsBatch))
         {
+            if (in2)
+            {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
+                ReadsBatch second;
+                if (in2->next(second, batch.size()) != batch.size()) fail("the two reads files hold different numbers of records");
+                const u64 shift = batch.codes.size();
+                batch.names.insert(batch.names.end(), second.names.begin(), second.names.end());
+                batch.codes.insert(batch.codes.end(), second.codes.begin(), second.codes.end());
+                batch.quals.insert(batch.quals.end(), second.quals.begin(), second.quals.end());
+                for (size_t i = 1; i < second.offs.size(); ++i) batch.offs.push_back(second.offs[i] + shift);
+            }
+            const size_t nPairs = batch.size() / 2;
             auto m0 = std::chrono::steady_clock::now();
             dy_reads * reads = nullptr;
             check(dy_reads_upload(ctx, batch.codes.data(), batch.offs.data(), (uint32_t)batch.size(), &reads));
@@ -153,7 +173,43 @@ int main(int argc, char ** argv)
                 const char * quals = batch.quals.data() + batch.offs[i];
                 const size_t len = (size_t)(batch.offs[i + 1] - batch.offs[i]);
                 const bool rev = r.mapped && r.primary.is_rev;
-                if (!r.mapped) rec += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
+                if (opt.params.paired)
+                {   // _writeMappedRead / _writeUnmappedRead for pairs (reference src/mapper_writer.h:268-293,347-400,515-571)
+                    const dy_read_result & mr = rr[i < nPairs ? i + nPairs : i - nPairs];
+                    unsigned flag = 1u | (i < nPairs ? 64u : 128u);
+                    if (!mr.mapped) flag |= 8;
+                    if (!r.mapped) flag |= 4;
+                    if (rev) flag |= 16;
+                    if (mr.mapped && mr.primary.is_rev) flag |= 32;
+                    long long tlen = 0;
+                    if (r.mapped && mr.mapped && r.paired)
+                    {
+                        const bool oneBeforeTwo = r.primary.begin < mr.primary.begin;
+                        if ((!r.primary.is_rev && mr.primary.is_rev && oneBeforeTwo) || (!mr.primary.is_rev && r.primary.is_rev && !oneBeforeTwo)) flag |= 2;
+                        if (r.primary.contig == mr.primary.contig)
+                            tlen = oneBeforeTwo ? (long long)mr.primary.begin + mr.primary.length - (long long)r.primary.begin
+                                                : (long long)mr.primary.begin - ((long long)r.primary.begin + r.primary.length);
+                    }
+                    rec += '\t'; appendUint(rec, flag); rec += '\t';
+                    const dy_match * posOf = r.mapped ? &r.primary : (mr.mapped ? &mr.primary : nullptr);
+                    if (posOf) { rec += dy_index_contig_name(idx, posOf->contig); rec += '\t'; appendUint(rec, (unsigned long long)posOf->begin + 1); }
+                    else rec += "*\t0";
+                    rec += '\t'; appendUint(rec, r.mapped ? r.mapq : 0); rec += '\t';
+                    if (r.mapped) for (uint32_t k = 0; k < r.cigar_len; ++k) { uint32_t op = cg[r.cigar_begin + k]; appendUint(rec, op >> 4); rec += "MID"[op & 15]; }
+                    else rec += '*';
+                    rec += '\t';
+                    if (mr.mapped)
+                    {
+                        if (posOf && posOf->contig == mr.primary.contig) rec += '='; else rec += dy_index_contig_name(idx, mr.primary.contig);
+                        rec += '\t'; appendUint(rec, (unsigned long long)mr.primary.begin + 1);
+                    }
+                    else if (r.mapped) { rec += "=\t"; appendUint(rec, (unsigned long long)r.primary.begin + 1); }
+                    else rec += "*\t0";
+                    rec += '\t';
+                    if (tlen < 0) { rec += '-'; appendUint(rec, (unsigned long long)(-tlen)); } else appendUint(rec, (unsigned long long)tlen);
+                    rec += '\t';
+                }
+                else if (!r.mapped) rec += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
                 else
                 {
                     rec += rev ? "\t16\t" : "\t0\t";

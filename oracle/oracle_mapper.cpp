@@ -4,6 +4,7 @@
 #include "dyo_dream.hpp"
 #include <iostream>
 #include <chrono>
+#include <memory>
 
 using namespace dyo;
 
@@ -29,11 +30,16 @@ int main(int argc, char ** argv)
             else if (a == "-rb" || a == "--reads-batch") opt.readsCount = (unsigned)std::stoul(next());
             else if (a == "-rg" || a == "--read-group") opt.readGroup = next();
             else if (a == "-sm" || a == "--secondary-matches") next();     // parsed under a legacy name by the reference: no-op
+            else if (a == "-ll" || a == "--library-length") opt.libraryLength = (unsigned)std::stoul(next());
+            else if (a == "-ld" || a == "--library-deviation") opt.libraryDev = (unsigned)std::stoul(next());
+            else if (a == "-i" || a == "--indel-rate") opt.indelRate = (float)(std::stoul(next()) / 100.0);
+            else if (a == "-ni" || a == "--no-indels") opt.verifyMatches = false;
             else if (a == "-v" || a == "--verbose") verbose = true;
             else if (a.size() > 1 && a[0] == '-') throw std::runtime_error("unknown option " + a);
             else pos.push_back(a);
         }
-        if (pos.size() != 2) throw std::runtime_error("usage: oracle_mapper [OPTIONS] <INDEX DIR> <READS>");
+        if (pos.size() != 2 && pos.size() != 3) throw std::runtime_error("usage: oracle_mapper [OPTIONS] <INDEX DIR> <READS> [<READS2>]");
+        const bool paired = pos.size() == 3;
         if (opt.sensitivity == FULL) throw std::runtime_error("-y full (edit-distance seeds) is not restated");
         for (int i = 0; i < argc; ++i) { if (i) opt.commandLine += ' '; opt.commandLine += argv[i]; }
         std::string dir = pos[0];
@@ -60,20 +66,24 @@ int main(int argc, char ** argv)
         DreamMapper mapper(idx, opt.useFilter ? &filter : nullptr, opt);
         mapper.writeHeader(os);
         SeqReader reader(pos[1]);
+        std::unique_ptr<SeqReader> reader2;
+        if (paired) reader2.reset(new SeqReader(pos[2]));
         u64 total = 0, mapped = 0;
         DreamStats stats;
         for (;;)
         {
             SeqRecords recs;
-            if (!reader.read(recs, opt.readsCount)) break;
+            size_t got = reader.read(recs, opt.readsCount);
+            if (!got) break;
+            if (paired && reader2->read(recs, got) != got) throw std::runtime_error("the two reads files hold different numbers of records");
             ReadBatch batch;
             for (size_t i = 0; i < recs.seqs.size(); ++i)
             {
                 if (recs.seqs[i].size() > 8191) throw std::runtime_error("Maximum read length exceeded.");
                 appendRead(batch, recs.names[i], recs.seqs[i], recs.quals[i]);
             }
-            std::vector<ReadResult> res = mapper.mapBatch(batch, verbose ? &stats : nullptr);
-            mapper.writeRecords(os, batch, res);
+            std::vector<ReadResult> res = paired ? mapper.mapBatchPaired(batch, verbose ? &stats : nullptr) : mapper.mapBatch(batch, verbose ? &stats : nullptr);
+            if (paired) mapper.writeRecordsPaired(os, batch, res); else mapper.writeRecords(os, batch, res);
             total += batch.size();
             for (auto & r : res) mapped += r.mapped;
         }

@@ -402,6 +402,42 @@ def test_paired_end_matches_oracle(dy, ctx, ob, tmp_path, use_filter, ll, ld, ve
     if oibf: oibf.close()
 
 
+def _write_fastq(path, codes, offs, lo, hi, suffix):
+    with open(path, "w") as f:
+        for i in range(lo, hi):
+            seq = "".join("ACGT"[c] for c in codes[int(offs[i]):int(offs[i + 1])])
+            f.write("@pair%d%s\n%s\n+\n%s\n" % (i - lo, suffix, seq, "I" * len(seq)))
+
+
+@pytest.mark.parametrize("extra", [[], ["-ll", "320", "-ld", "30", "-s", "2"], ["-ni"]])
+def test_cli_paired_end_sam_equals_oracle_cli(product_build, oracle_build, ob, tmp_path, extra):
+    """Two reads files -> paired SAM (flags, RNEXT/PNEXT/TLEN, pair MAPQ): the product CLI's text equals the oracle CLI's.
+    Parity unpinned by reference fixtures (the reference ships no paired gold output)."""
+    rng = np.random.default_rng(4242)
+    n_bins = 4
+    genomes = [rng.integers(0, 4, 40000, dtype=np.uint8) for _ in range(n_bins)]
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    fpath = str(tmp_path / "f.filter")
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    ob.build_filter(fpath, n_bins, 3, 16, 1 << 24, np.concatenate(genomes), goffs)
+    n_pairs = 700
+    codes, offs = _make_pairs(rng, genomes, n_pairs, 100)
+    f1, f2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    _write_fastq(f1, codes, offs, 0, n_pairs, "/1"); _write_fastq(f2, codes, offs, n_pairs, 2 * n_pairs, "/2")
+    mine, ref = str(tmp_path / "mine.sam"), str(tmp_path / "ref.sam")
+    subprocess.check_call([os.path.join(product_build, "dream_yara_mapper"), "-fi", fpath, idx_dir + "/", f1, f2, "-o", mine, "-e", "3"] + extra)
+    subprocess.check_call([os.path.join(oracle_build, "oracle_mapper"), "-fi", fpath, idx_dir + "/", f1, f2, "-o", ref, "-e", "3"] + extra)
+    a, b = sam_records(mine), sam_records(ref)
+    assert a[:3 + n_bins - 1] == b[:3 + n_bins - 1]          # header (minus @PG)
+    a, b = [r for r in a if r[0] != "@"], [r for r in b if r[0] != "@"]
+    assert len(a) == len(b) == 2 * n_pairs
+    assert [(x, y) for x, y in zip(a, b) if x != y] == []
+    flags = [int(r.split("\t")[1]) for r in a]
+    assert sum(1 for f in flags if f & 2) > n_pairs          # most pairs are proper
+
+
 # ---------------------------------------------------------------------------------------------- larger sizes: properties
 def test_error_free_reads_map_to_their_origin_at_scale(dy, ctx, product_build, tmp_path):
     from dream_yara_amd import synth
