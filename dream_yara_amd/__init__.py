@@ -92,7 +92,15 @@ SYMBOLS = [
     ("dy_result_cigars", _P, [_P]),
     ("dy_result_free", None, [_P]),
     ("dy_map_get_stats", C.c_int, [_P, C.POINTER(MapStats)]),
+    ("dy_index_load_sharded", C.c_int, [_P, C.c_char_p, C.c_uint32, _P, C.POINTER(_P)]),
+    ("dy_shard_plan", C.c_int, [_P, _P, C.c_uint32, _P, _P, _P]),
+    ("dy_shard_pack", C.c_int, [_P, _P, _P, _P, _P, _P]),
+    ("dy_reads_from_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
+    ("dy_map_bins", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.POINTER(C.c_uint64)]),
+    ("dy_raw_pack", C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
+    ("dy_finalize_raw", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.c_uint64, _P, C.POINTER(_P)]),
 ]
+RAW_MATCH_BYTES = 16
 
 _lib = None
 
@@ -191,6 +199,16 @@ def threshold(error_rate, kmer_size, read_len):
 
 
 class Reads:
+    @classmethod
+    def from_device(cls, ctx, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins):
+        """A batch from device buffers in dy_shard_pack's layout (raw device addresses)."""
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.n = ctx, ctx.lib, n_reads
+        h = _P()
+        _check(self.lib.dy_reads_from_device(ctx.h, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, C.byref(h)))
+        self.h = h
+        return self
+
     def __init__(self, ctx, codes, offs):
         self.ctx, self.lib = ctx, ctx.lib
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
@@ -207,11 +225,18 @@ class Reads:
 
 
 class Index:
-    def __init__(self, ctx, directory, n_bins):
+    def __init__(self, ctx, directory, n_bins, owned=None):
+        """owned = None: every bin resident; else n_bins flags, FM structures of the flagged bins only (dy_index_load_sharded)."""
         self.ctx, self.lib = ctx, ctx.lib
         h = _P()
-        _check(self.lib.dy_index_load(ctx.h, os.fsencode(directory), n_bins, C.byref(h)))
+        if owned is None:
+            _check(self.lib.dy_index_load(ctx.h, os.fsencode(directory), n_bins, C.byref(h)))
+        else:
+            owned = np.ascontiguousarray(owned, dtype=np.uint8)
+            assert owned.size == n_bins
+            _check(self.lib.dy_index_load_sharded(ctx.h, os.fsencode(directory), n_bins, owned.ctypes.data, C.byref(h)))
         self.h = h
+        self.n_bins = n_bins
 
     def contig_names(self):
         return [self.lib.dy_index_contig_name(self.h, c).decode() for c in range(self.lib.dy_index_contigs(self.h))]
@@ -276,6 +301,42 @@ def map_reads(ctx, index, reads, params, asynchronous=False):
     h = _P()
     fn = ctx.lib.dy_map_reads_async if asynchronous else ctx.lib.dy_map_reads
     _check(fn(ctx.h, index.h, reads.h, C.byref(params), C.byref(h)))
+    return Result(ctx, h, reads.n)
+
+
+def shard_plan(ctx, reads, owner_masks):
+    """owner_masks: (n_ranks, W) uint64.  Returns (reads per destination rank, bases per destination rank)."""
+    owner_masks = np.ascontiguousarray(owner_masks, dtype=np.uint64)
+    n_ranks = owner_masks.shape[0]
+    n_to = np.zeros(n_ranks, np.uint32); b_to = np.zeros(n_ranks, np.uint64)
+    _check(ctx.lib.dy_shard_plan(ctx.h, reads.h, n_ranks, owner_masks.ctypes.data, n_to.ctypes.data, b_to.ctypes.data))
+    return n_to, b_to
+
+
+def shard_pack(ctx, reads, ids_ptr, lens_ptr, masks_ptr, seqs_ptr):
+    _check(ctx.lib.dy_shard_pack(ctx.h, reads.h, ids_ptr, lens_ptr, masks_ptr, seqs_ptr))
+
+
+def map_bins(ctx, index, reads, params):
+    """K2 + K3 for the resident bins.  Returns (items per bin, number of raw matches left in the context)."""
+    loads = np.zeros(index.n_bins, np.uint32)
+    n_raw = C.c_uint64(0)
+    _check(ctx.lib.dy_map_bins(ctx.h, index.h, reads.h, C.byref(params), loads.ctypes.data, C.byref(n_raw)))
+    return loads, int(n_raw.value)
+
+
+def raw_pack(ctx, seg_starts, ids_ptr, raw_out_ptr):
+    seg_starts = np.ascontiguousarray(seg_starts, dtype=np.uint32)
+    n_ranks = seg_starts.size - 1
+    n_to = np.zeros(n_ranks, np.uint64)
+    _check(ctx.lib.dy_raw_pack(ctx.h, n_ranks, seg_starts.ctypes.data, ids_ptr, raw_out_ptr, n_to.ctypes.data))
+    return n_to
+
+
+def finalize_raw(ctx, index, reads, params, raw_ptr, n_raw, bin_loads):
+    bin_loads = np.ascontiguousarray(bin_loads, dtype=np.uint32)
+    h = _P()
+    _check(ctx.lib.dy_finalize_raw(ctx.h, index.h, reads.h, C.byref(params), raw_ptr, n_raw, bin_loads.ctypes.data, C.byref(h)))
     return Result(ctx, h, reads.n)
 
 

@@ -16,6 +16,7 @@
 #include "map_kernels.h"
 #include "finalize_kernels.h"
 #include "pe_kernels.h"
+#include "shard_kernels.h"
 
 using namespace dy;
 
@@ -79,8 +80,12 @@ struct dy_ctx
     // workspaces (grow-only, reused across batches)
     DevBuf peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
-           cursor, gp, aux, marr, maux, dp, scanTmp;
+           cursor, gp, aux, marr, maux, dp, scanTmp,
+           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg;
     size_t poolCap = 0;
+    // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
+    const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
+    u32 lastRaw = 0; bool rawValid = false;
 };
 
 struct dy_ibf
@@ -108,7 +113,9 @@ struct dy_index
     std::vector<std::string> contigNames;
     std::vector<u64> contigLengths;
     DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable;
-    bool hasFullSa = false, multiContig = false;
+    bool hasFullSa = false, multiContig = false, sharded = false;
+    std::vector<u64> ownedMask;     // bins whose FM structures are resident (all of them unless loaded sharded)
+    DevBuf dOwnedMask;
     u32 prefixQ = 0;
     IndexView view() const
     {
@@ -157,6 +164,188 @@ static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & r
                        nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2);
 }
 
+// Work list + K2 + K3: (read,bin) items of the masks on `reads` -> raw matches in ctx->pool, per-read counts in ctx->readMatchCount.
+static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, u32 S0, u32 & nItemsOut, u32 & nPoolOut)
+{
+        hipStream_t st = ctx->stream;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
+        // ---- work list (bin-major)
+        HIP_CHECK(hipEventRecord(ctx->ev[2], st));
+        const u32 nWaves = (nReads + 63) / 64;
+        const size_t nCells = (size_t)nBins * nWaves;
+        ctx->waveCounts.reserve((nCells + 1) * 4); ctx->waveOffsets.reserve((nCells + 1) * 4);
+        ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
+        HIP_CHECK(hipMemsetAsync(ctx->waveCounts.as<u32>() + nCells, 0, 4, st));
+        hipLaunchKernelGGL(k_items_count, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins, ctx->waveCounts.as<u32>());
+        {
+            size_t tmpBytes = 0;
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
+            ctx->scanTmp.reserve(tmpBytes + 64);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
+        }
+        hipLaunchKernelGGL(k_items_bin_starts, dim3((nBins + 1 + 63) / 64), dim3(64), 0, st, ctx->waveOffsets.as<u32>(), ctx->waveOffsets.as<u32>() + nCells,
+                           nWaves, nBins, ctx->binStart.as<u32>(), ctx->binOrderRank.as<u32>());
+        u32 nItems = 0;
+        HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (ctx->ibfTimingPending) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; ctx->ibfTimingPending = false; }
+        ctx->stats.items = nItems;
+        ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
+        if (nItems)
+            hipLaunchKernelGGL(k_items_scatter, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins,
+                               ctx->waveOffsets.as<u32>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>());
+        HIP_CHECK(hipEventRecord(ctx->ev[3], st));
+
+        // ---- K2: exact search of the round-0 seeds
+        const IndexView ix = idx->view();
+        ReadsView rv; rv.seqs = reads->seqs.as<u8>(); rv.seqsRc = reads->seqsRc.as<u8>(); rv.offs = reads->offs.as<u64>(); rv.nReads = nReads;
+        MapParams mp; mp.errorRate = p->error_rate; mp.strataRate = p->strata_rate; mp.sensitivity = p->sensitivity; mp.hitsThreshold = p->hits_threshold;
+        ctx->hits0.reserve((size_t)nItems * 2 * S0 * sizeof(uint2) + 64);
+        if (nItems)
+        {
+            u64 threads = (u64)nItems * 2 * S0;
+            hipLaunchKernelGGL(k_seed_search, dim3((u32)(((threads + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                               nItems, S0, mp.errorRate, ctx->hits0.as<uint2>());
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev[4], st));
+
+        // ---- K3: classify, rank, locate, extend -> raw match pool (grown and re-run on overflow)
+        ctx->counters.reserve(64);
+        ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
+        if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
+        u32 hostCounters[4] = {0, 0, 0, 0};     // [0] pool count, [1] overflow flag, [2] hard items
+        const int nw = (int)((reads->maxLen + 63) / 64);
+        for (;;)
+        {
+            ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
+            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 32, st));
+            HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
+            MatchSink sink; sink.debugFlags = getenv("DY_DEBUG_EXTEND") ? (u32)atoi(getenv("DY_DEBUG_EXTEND")) : 0; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
+            sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
+            if (nItems)
+            {
+                if (nw <= 2) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink);
+                else if (nw <= 4) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink);
+                else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink);
+                else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink);
+                HIP_CHECK(hipGetLastError());
+            }
+            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, 16, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (!hostCounters[1]) break;
+            if (hostCounters[0] >= 0xFFFFFFF0u) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+            ctx->poolCap = (size_t)hostCounters[0] + (size_t)hostCounters[0] / 4 + 1024;
+            ctx->stats.pool_retries++;
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev[5], st));
+        const u32 nPool = hostCounters[0];
+        ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2];
+
+        nItemsOut = nItems; nPoolOut = nPool;
+}
+
+// Group raw matches by read (counts in ctx->readMatchCount) and run the per-read aggregation (K4 / paired-end stages).
+static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, dy_result * res, const RawMatch * pool, u32 nPool,
+                        u32 nItems, u32 maxMatchErr)
+{
+        hipStream_t st = ctx->stream;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
+        const bool paired = p->paired != 0;
+        const IndexView ix = idx->view();
+        ReadsView rv; rv.seqs = reads->seqs.as<u8>(); rv.seqsRc = reads->seqsRc.as<u8>(); rv.offs = reads->offs.as<u64>(); rv.nReads = nReads;
+        // ---- group by read, then per-read aggregation
+        ctx->readStart.reserve((size_t)(nReads + 1) * 4);
+        size_t tmpBytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->readMatchCount.as<u32>(), ctx->readStart.as<u32>(), (int)(nReads + 1), st));
+        ctx->scanTmp.reserve(tmpBytes + 64);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->readMatchCount.as<u32>(), ctx->readStart.as<u32>(), (int)(nReads + 1), st));
+        ctx->cursor.reserve((size_t)nReads * 4 + 64);
+        HIP_CHECK(hipMemsetAsync(ctx->cursor.p, 0, (size_t)nReads * 4, st));
+        ctx->gp.reserve((size_t)nPool * sizeof(RawMatch) + 64);
+        if (nPool)
+            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, pool, nPool, ctx->readStart.as<u32>(),
+                               ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>());
+        ctx->aux.reserve((size_t)nPool * 16 + 64);
+        const size_t setCap = paired ? (size_t)nPool * 3 + nItems : (size_t)nPool * 3;
+        res->setCap = setCap;
+        ctx->marr.reserve(setCap * sizeof(RawMatch) + 64);
+        ctx->maux.reserve(setCap * 2 * 4 + 64);
+        res->outSet.reserve(setCap * sizeof(OutMatch) + 64);
+        const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
+        const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
+        ctx->dp.reserve(dpStride * finWaves + 64);
+        FinalizeArgs fa;
+        fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.nReads = nReads;
+        fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
+        fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
+        fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
+        fa.debugFlags = getenv("DY_DEBUG_FINALIZE") ? (u32)atoi(getenv("DY_DEBUG_FINALIZE")) : 0;
+        ctx->complexList.reserve((size_t)nReads * 4 + 64);
+        u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
+        fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
+        if (!paired)
+        {
+            ctx->alignList.reserve((size_t)nReads * 4 + 64);
+            u32 * alignCount = ctx->counters.as<u32>() + 4;
+            ctx->smallList.reserve((size_t)nReads * 4 + 64);
+            u32 * smallCount = ctx->counters.as<u32>() + 5;
+            hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
+                               ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
+            hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
+            hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
+            hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
+        }
+        else
+        {
+            // ---- paired-end stages (pe_kernels.h)
+            ctx->peItems.reserve((size_t)nItems * sizeof(PeItem) + 64);
+            ctx->peU2.reserve((size_t)nPool * sizeof(RawMatch) + 64);
+            ctx->peLib.reserve((size_t)nBins * sizeof(PeLibrary) + 64);
+            ctx->peLens.reserve((size_t)nItems * 4 + 64); ctx->peIdx.reserve((size_t)nItems * 4 + 64);
+            ctx->peHasRescue.reserve((size_t)nReads * 4 + 64); ctx->peJobs.reserve((size_t)nItems * 4 + 64);
+            HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
+            HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
+            PeView V;
+            V.items = ctx->peItems.as<PeItem>(); V.u2 = ctx->peU2.as<RawMatch>(); V.itemRead = ctx->itemRead.as<u32>(); V.itemBin = ctx->itemBin.as<u16>();
+            V.binStart = ctx->binStart.as<u32>(); V.masks = reads->masks.as<u64>(); V.W = W; V.nBins = nBins; V.nPairs = nReads / 2; V.nItems = nItems;
+            V.lib = ctx->peLib.as<PeLibrary>(); V.libLens = ctx->peLens.as<u32>(); V.libIdx = ctx->peIdx.as<u32>();
+            V.optLibLength = p->library_length; V.optLibDev = p->library_dev; V.verify = p->verify_matches;
+            V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
+            hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V);
+            hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(64), 0, st, V);
+            if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
+            if (p->verify_matches && nItems)
+            {
+                std::vector<PeLibrary> hostLib(nBins);
+                HIP_CHECK(hipMemcpyAsync(hostLib.data(), ctx->peLib.p, (size_t)nBins * sizeof(PeLibrary), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                u32 maxWindow = 0;
+                for (auto & l : hostLib) maxWindow = std::max(maxWindow, 6 * l.dev);
+                if (maxWindow)
+                {
+                    u32 * jobCount = ctx->counters.as<u32>() + 6;
+                    hipLaunchKernelGGL(k_pe_rescue_jobs, dim3((nItems + 255) / 256), dim3(256), 0, st, V, ctx->peJobs.as<u32>(), jobCount);
+                    const u32 rescueBlocks = 512, rescueWaves = rescueBlocks * 4;
+                    const size_t stride = (peRescueScratchBytes(reads->maxLen, maxWindow) + 63) & ~(size_t)63;
+                    ctx->peScratch.reserve(stride * rescueWaves + 64);
+                    hipLaunchKernelGGL(k_pe_rescue, dim3(rescueBlocks), dim3(256), 0, st, fa, V, ctx->peJobs.as<u32>(), jobCount, ctx->peScratch.as<u8>(), stride, maxWindow);
+                }
+            }
+            // room per read in the main mapper's match array: 3 per raw match + one per selected bin (a rescued mate)
+            ctx->peMCounts.reserve((size_t)(nReads + 1) * 4 + 64); ctx->peMStart.reserve((size_t)(nReads + 1) * 4 + 64);
+            hipLaunchKernelGGL(k_pe_mcounts, dim3((nReads + 1 + 255) / 256), dim3(256), 0, st, ctx->readMatchCount.as<u32>(), reads->masks.as<u64>(), W, nReads, ctx->peMCounts.as<u32>());
+            {
+                size_t tb = 0;
+                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
+                ctx->scanTmp.reserve(tb + 64);
+                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
+            }
+            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->complexList.as<u32>(), complexCount);
+            hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
+        }
+        HIP_CHECK(hipGetLastError());
+}
+
 // MAPQ — reference src/bits_matches.h:898-949, src/mapper_writer.h:221-225 (fp64, host libm like the reference)
 static double residualWeight(double errorRate) { double p = std::pow(10.0, std::min(2.0, 100.0 * errorRate - 7.0)); return p / (1.0 - p); }
 static double matchWeight(double errorRate, double optimalRate) { return (1.0 - errorRate) / std::pow(10.0, 300.0 * (errorRate - optimalRate)); }
@@ -169,6 +358,24 @@ static unsigned mapqOf(unsigned errors, unsigned readLen, u64 best, u64 sub)
 }
 
 // ---------------------------------------------------------------------------------------------------
+static std::unique_ptr<dy_result> makeResult(dy_ctx * ctx, const dy_reads * reads, u32 maxMatchErr)
+{
+    std::unique_ptr<dy_result> res(new dy_result);
+    res->ctx = ctx; res->nReads = reads->n; res->cigarStride = 2 * maxMatchErr + 1;
+    res->out.reserve((size_t)reads->n * sizeof(ReadOut) + 64);
+    res->cigars.reserve((size_t)reads->n * res->cigarStride * 4 + 64);
+    return res;
+}
+
+template <typename TIn, typename TOut>
+static void exclusiveSum(dy_ctx * ctx, const TIn * in, TOut * out, size_t n)
+{
+    size_t tmpBytes = 0;
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, in, out, (int)n, ctx->stream));
+    ctx->scanTmp.reserve(tmpBytes + 64);
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, in, out, (int)n, ctx->stream));
+}
+
 extern "C" {
 
 int dy_abi_version(void) { return DY_ABI_VERSION; }
@@ -385,7 +592,7 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
 }
 
 // ---- index --------------------------------------------------------------------------------------------
-int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** out)
+static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint8_t * owned, dy_index ** out)
 {
     return guarded([&] {
         if (!ctx || !dir || !out) throw DyError(DY_EINVAL, "dy_index_load: NULL argument");
@@ -394,9 +601,13 @@ int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** o
         std::string d(dir);
         while (d.size() > 1 && d.back() == '/') d.pop_back();
         HostIndex H;
-        for (u32 b = 0; b < n_bins; ++b) appendBin(H, d + "/" + std::to_string(b));
+        for (u32 b = 0; b < n_bins; ++b) appendBin(H, d + "/" + std::to_string(b), !owned || owned[b]);
         std::unique_ptr<dy_index> idx(new dy_index);
         idx->ctx = ctx;
+        idx->sharded = owned != nullptr;
+        idx->ownedMask.assign((n_bins + 63) / 64, 0);
+        for (u32 b = 0; b < n_bins; ++b) if (!owned || owned[b]) idx->ownedMask[b / 64] |= 1ull << (b % 64);
+        upload(idx->dOwnedMask, idx->ownedMask);
         idx->bins = H.bins; idx->contigNames = H.contigNames; idx->contigLengths = H.contigLengths;
         u64 totalRows = 0;
         for (auto & bd : H.bins) { bd.saFullOff = totalRows; totalRows += bd.n; idx->multiContig |= bd.nContigs > 1; }
@@ -413,6 +624,7 @@ int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** o
             if (idx->multiContig) idx->saFullContig.reserve(totalRows * 2 + 64);
             IndexView v = idx->view();
             for (u32 b = 0; b < n_bins; ++b)
+                if (H.bins[b].n)
                 hipLaunchKernelGGL(k_expand_sa, dim3((H.bins[b].n + 255) / 256), dim3(256), 0, ctx->stream, v, b, idx->saFullOffset.as<u32>(),
                                    idx->multiContig ? idx->saFullContig.as<u16>() : nullptr);
             HIP_CHECK(hipGetLastError());
@@ -423,24 +635,27 @@ int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** o
         {
             HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
             u32 q = 12;
-            while (q > 0 && ((size_t)n_bins << (2 * q)) * sizeof(uint2) > freeB / 4) --q;
+            u32 nOwned = 0;
+            for (u32 b = 0; b < n_bins; ++b) nOwned += H.bins[b].n ? 1 : 0;
+            while (q > 0 && ((size_t)std::max(nOwned, 1u) << (2 * q)) * sizeof(uint2) > freeB / 4) --q;
             if (getenv("DY_PREFIX_Q")) q = std::min<u32>(q, (u32)atoi(getenv("DY_PREFIX_Q")));
             if (q >= 4)
             {
                 const size_t perBin = (size_t)1 << (2 * q);
-                idx->prefixTable.reserve(perBin * n_bins * sizeof(uint2) + 64);
+                idx->prefixTable.reserve(perBin * std::max(nOwned, 1u) * sizeof(uint2) + 64);
                 DevBuf ping, pong;
                 ping.reserve((perBin / 4) * sizeof(uint2) + 64); pong.reserve((perBin / 4) * sizeof(uint2) + 64);
-                for (u32 b = 0; b < n_bins; ++b) idx->bins[b].prefixOff = perBin * b;
+                { u32 slot = 0; for (u32 b = 0; b < n_bins; ++b) idx->bins[b].prefixOff = perBin * (H.bins[b].n ? slot++ : 0); }
                 upload(idx->dBins, idx->bins);
                 IndexView v = idx->view();
                 for (u32 b = 0; b < n_bins; ++b)
                 {
+                    if (!H.bins[b].n) continue;
                     const uint2 * parent = nullptr;
                     for (u32 level = 1; level <= q; ++level)
                     {
                         const u32 nChild = 1u << (2 * level);
-                        uint2 * child = level == q ? idx->prefixTable.as<uint2>() + perBin * b : ((level & 1) ? ping.as<uint2>() : pong.as<uint2>());
+                        uint2 * child = level == q ? idx->prefixTable.as<uint2>() + idx->bins[b].prefixOff : ((level & 1) ? ping.as<uint2>() : pong.as<uint2>());
                         hipLaunchKernelGGL(k_prefix_level, dim3((nChild + 255) / 256), dim3(256), 0, ctx->stream, v, b, parent, child, nChild);
                         parent = child;
                     }
@@ -452,6 +667,13 @@ int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** o
         }
         *out = idx.release();
     });
+}
+
+int dy_index_load(dy_ctx * ctx, const char * dir, uint32_t n_bins, dy_index ** out) { return loadIndex(ctx, dir, n_bins, nullptr, out); }
+int dy_index_load_sharded(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint8_t * owned, dy_index ** out)
+{
+    if (!owned) { g_lastError = "dy_index_load_sharded: owned is NULL"; return DY_EINVAL; }
+    return loadIndex(ctx, dir, n_bins, owned, out);
 }
 
 uint32_t dy_index_bins(const dy_index * idx) { return idx ? (uint32_t)idx->bins.size() : 0; }
@@ -474,6 +696,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         if (!ctx || !idx || !reads || !p || !out) throw DyError(DY_EINVAL, "dy_map_reads: NULL argument");
         if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
         if (p->sensitivity > 1) throw DyError(DY_EUNSUPPORTED, "sensitivity 'full' (edit-distance seeds) is not implemented");
+        if (idx->sharded) throw DyError(DY_EINVAL, "this index holds a shard of the bins: use dy_map_bins / dy_finalize_raw");
         if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
         HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
@@ -506,170 +729,10 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
         if (nReads == 0) { *out = res.release(); return; }
 
-        // ---- work list (bin-major)
-        HIP_CHECK(hipEventRecord(ctx->ev[2], st));
-        const u32 nWaves = (nReads + 63) / 64;
-        const size_t nCells = (size_t)nBins * nWaves;
-        ctx->waveCounts.reserve((nCells + 1) * 4); ctx->waveOffsets.reserve((nCells + 1) * 4);
-        ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
-        HIP_CHECK(hipMemsetAsync(ctx->waveCounts.as<u32>() + nCells, 0, 4, st));
-        hipLaunchKernelGGL(k_items_count, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins, ctx->waveCounts.as<u32>());
-        {
-            size_t tmpBytes = 0;
-            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
-            ctx->scanTmp.reserve(tmpBytes + 64);
-            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
-        }
-        hipLaunchKernelGGL(k_items_bin_starts, dim3((nBins + 1 + 63) / 64), dim3(64), 0, st, ctx->waveOffsets.as<u32>(), ctx->waveOffsets.as<u32>() + nCells,
-                           nWaves, nBins, ctx->binStart.as<u32>(), ctx->binOrderRank.as<u32>());
-        u32 nItems = 0;
-        HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (ctx->ibfTimingPending) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; ctx->ibfTimingPending = false; }
-        ctx->stats.items = nItems;
-        ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
-        if (nItems)
-            hipLaunchKernelGGL(k_items_scatter, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins,
-                               ctx->waveOffsets.as<u32>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>());
-        HIP_CHECK(hipEventRecord(ctx->ev[3], st));
-
-        // ---- K2: exact search of the round-0 seeds
-        const IndexView ix = idx->view();
-        ReadsView rv; rv.seqs = reads->seqs.as<u8>(); rv.seqsRc = reads->seqsRc.as<u8>(); rv.offs = reads->offs.as<u64>(); rv.nReads = nReads;
-        MapParams mp; mp.errorRate = p->error_rate; mp.strataRate = p->strata_rate; mp.sensitivity = p->sensitivity; mp.hitsThreshold = p->hits_threshold;
-        ctx->hits0.reserve((size_t)nItems * 2 * S0 * sizeof(uint2) + 64);
-        if (nItems)
-        {
-            u64 threads = (u64)nItems * 2 * S0;
-            hipLaunchKernelGGL(k_seed_search, dim3((u32)(((threads + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
-                               nItems, S0, mp.errorRate, ctx->hits0.as<uint2>());
-        }
-        HIP_CHECK(hipEventRecord(ctx->ev[4], st));
-
-        // ---- K3: classify, rank, locate, extend -> raw match pool (grown and re-run on overflow)
-        ctx->counters.reserve(64);
-        ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
-        if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
-        u32 hostCounters[4] = {0, 0, 0, 0};     // [0] pool count, [1] overflow flag, [2] hard items
-        const int nw = (int)((reads->maxLen + 63) / 64);
-        for (;;)
-        {
-            ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
-            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 32, st));
-            HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
-            MatchSink sink; sink.debugFlags = getenv("DY_DEBUG_EXTEND") ? (u32)atoi(getenv("DY_DEBUG_EXTEND")) : 0; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
-            sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
-            if (nItems)
-            {
-                if (nw <= 2) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink);
-                else if (nw <= 4) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink);
-                else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink);
-                else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink);
-                HIP_CHECK(hipGetLastError());
-            }
-            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, 16, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (!hostCounters[1]) break;
-            if (hostCounters[0] >= 0xFFFFFFF0u) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
-            ctx->poolCap = (size_t)hostCounters[0] + (size_t)hostCounters[0] / 4 + 1024;
-            ctx->stats.pool_retries++;
-        }
-        HIP_CHECK(hipEventRecord(ctx->ev[5], st));
-        const u32 nPool = hostCounters[0];
-        ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2];
+        u32 nItems = 0, nPool = 0;
+        runSearchExtend(ctx, idx, reads, p, S0, nItems, nPool);
         res->nPool = nPool;
-
-        // ---- group by read, then per-read aggregation
-        ctx->readStart.reserve((size_t)(nReads + 1) * 4);
-        size_t tmpBytes = 0;
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->readMatchCount.as<u32>(), ctx->readStart.as<u32>(), (int)(nReads + 1), st));
-        ctx->scanTmp.reserve(tmpBytes + 64);
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->readMatchCount.as<u32>(), ctx->readStart.as<u32>(), (int)(nReads + 1), st));
-        ctx->cursor.reserve((size_t)nReads * 4 + 64);
-        HIP_CHECK(hipMemsetAsync(ctx->cursor.p, 0, (size_t)nReads * 4, st));
-        ctx->gp.reserve((size_t)nPool * sizeof(RawMatch) + 64);
-        if (nPool)
-            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, ctx->pool.as<RawMatch>(), nPool, ctx->readStart.as<u32>(),
-                               ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>());
-        ctx->aux.reserve((size_t)nPool * 16 + 64);
-        const size_t setCap = paired ? (size_t)nPool * 3 + nItems : (size_t)nPool * 3;
-        res->setCap = setCap;
-        ctx->marr.reserve(setCap * sizeof(RawMatch) + 64);
-        ctx->maux.reserve(setCap * 2 * 4 + 64);
-        res->outSet.reserve(setCap * sizeof(OutMatch) + 64);
-        const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
-        const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
-        ctx->dp.reserve(dpStride * finWaves + 64);
-        FinalizeArgs fa;
-        fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.nReads = nReads;
-        fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
-        fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
-        fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
-        fa.debugFlags = getenv("DY_DEBUG_FINALIZE") ? (u32)atoi(getenv("DY_DEBUG_FINALIZE")) : 0;
-        ctx->complexList.reserve((size_t)nReads * 4 + 64);
-        u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
-        fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
-        if (!paired)
-        {
-            ctx->alignList.reserve((size_t)nReads * 4 + 64);
-            u32 * alignCount = ctx->counters.as<u32>() + 4;
-            ctx->smallList.reserve((size_t)nReads * 4 + 64);
-            u32 * smallCount = ctx->counters.as<u32>() + 5;
-            hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
-                               ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
-            hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
-            hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
-            hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
-        }
-        else
-        {
-            // ---- paired-end stages (pe_kernels.h)
-            ctx->peItems.reserve((size_t)nItems * sizeof(PeItem) + 64);
-            ctx->peU2.reserve((size_t)nPool * sizeof(RawMatch) + 64);
-            ctx->peLib.reserve((size_t)nBins * sizeof(PeLibrary) + 64);
-            ctx->peLens.reserve((size_t)nItems * 4 + 64); ctx->peIdx.reserve((size_t)nItems * 4 + 64);
-            ctx->peHasRescue.reserve((size_t)nReads * 4 + 64); ctx->peJobs.reserve((size_t)nItems * 4 + 64);
-            HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
-            HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
-            PeView V;
-            V.items = ctx->peItems.as<PeItem>(); V.u2 = ctx->peU2.as<RawMatch>(); V.itemRead = ctx->itemRead.as<u32>(); V.itemBin = ctx->itemBin.as<u16>();
-            V.binStart = ctx->binStart.as<u32>(); V.masks = reads->masks.as<u64>(); V.W = W; V.nBins = nBins; V.nPairs = nReads / 2; V.nItems = nItems;
-            V.lib = ctx->peLib.as<PeLibrary>(); V.libLens = ctx->peLens.as<u32>(); V.libIdx = ctx->peIdx.as<u32>();
-            V.optLibLength = p->library_length; V.optLibDev = p->library_dev; V.verify = p->verify_matches;
-            V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
-            hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V);
-            hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(64), 0, st, V);
-            if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
-            if (p->verify_matches && nItems)
-            {
-                std::vector<PeLibrary> hostLib(nBins);
-                HIP_CHECK(hipMemcpyAsync(hostLib.data(), ctx->peLib.p, (size_t)nBins * sizeof(PeLibrary), hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-                u32 maxWindow = 0;
-                for (auto & l : hostLib) maxWindow = std::max(maxWindow, 6 * l.dev);
-                if (maxWindow)
-                {
-                    u32 * jobCount = ctx->counters.as<u32>() + 6;
-                    hipLaunchKernelGGL(k_pe_rescue_jobs, dim3((nItems + 255) / 256), dim3(256), 0, st, V, ctx->peJobs.as<u32>(), jobCount);
-                    const u32 rescueBlocks = 512, rescueWaves = rescueBlocks * 4;
-                    const size_t stride = (peRescueScratchBytes(reads->maxLen, maxWindow) + 63) & ~(size_t)63;
-                    ctx->peScratch.reserve(stride * rescueWaves + 64);
-                    hipLaunchKernelGGL(k_pe_rescue, dim3(rescueBlocks), dim3(256), 0, st, fa, V, ctx->peJobs.as<u32>(), jobCount, ctx->peScratch.as<u8>(), stride, maxWindow);
-                }
-            }
-            // room per read in the main mapper's match array: 3 per raw match + one per selected bin (a rescued mate)
-            ctx->peMCounts.reserve((size_t)(nReads + 1) * 4 + 64); ctx->peMStart.reserve((size_t)(nReads + 1) * 4 + 64);
-            hipLaunchKernelGGL(k_pe_mcounts, dim3((nReads + 1 + 255) / 256), dim3(256), 0, st, ctx->readMatchCount.as<u32>(), reads->masks.as<u64>(), W, nReads, ctx->peMCounts.as<u32>());
-            {
-                size_t tb = 0;
-                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
-                ctx->scanTmp.reserve(tb + 64);
-                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
-            }
-            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->complexList.as<u32>(), complexCount);
-            hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
-        }
-        HIP_CHECK(hipGetLastError());
+        runFinalize(ctx, idx, reads, p, res.get(), ctx->pool.as<RawMatch>(), nPool, nItems, maxMatchErr);
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
 
         res->readLens = reads->lens;       // for the host-side MAPQ
@@ -743,6 +806,210 @@ int dy_map_get_stats(const dy_ctx * ctx, dy_map_stats * s)
     if (!ctx || !s) { g_lastError = "NULL argument"; return DY_EINVAL; }
     *s = ctx->stats;
     return DY_OK;
+}
+
+// ---- bins sharded over ranks --------------------------------------------------------------------------
+int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const uint64_t * owner_masks, uint32_t * n_reads_to, uint64_t * n_bases_to)
+{
+    return guarded([&] {
+        if (!ctx || !reads || !owner_masks || !n_reads_to || !n_bases_to) throw DyError(DY_EINVAL, "dy_shard_plan: NULL argument");
+        if (reads->ctx != ctx) throw DyError(DY_EINVAL, "reads belong to a different context");
+        if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
+        if (!reads->maskW) throw DyError(DY_EINVAL, "dy_ibf_query must run on these reads first");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 n = reads->n, W = reads->maskW;
+        const u64 total = (u64)n_ranks * n;
+        if (total + 1 > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "ranks x reads too large for one plan");
+        ctx->planReads = nullptr;
+        ctx->shOwner.reserve((size_t)n_ranks * W * 8 + 64);
+        HIP_CHECK(hipMemcpyAsync(ctx->shOwner.p, owner_masks, (size_t)n_ranks * W * 8, hipMemcpyHostToDevice, ctx->stream));
+        ctx->shCnt.reserve((total + 1) * 4); ctx->shCntOff.reserve((total + 1) * 4);
+        ctx->shLen.reserve((total + 1) * 8); ctx->shLenOff.reserve((total + 1) * 8);
+        ctx->shTotals.reserve((size_t)(n_ranks + 1) * 2 * 8 + 64);
+        hipLaunchKernelGGL(k_shard_flags, dim3((u32)((total + 1 + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), reads->offs.as<u64>(), n, W,
+                           ctx->shOwner.as<u64>(), n_ranks, ctx->shCnt.as<u32>(), ctx->shLen.as<u64>());
+        exclusiveSum(ctx, ctx->shCnt.as<u32>(), ctx->shCntOff.as<u32>(), total + 1);
+        exclusiveSum(ctx, ctx->shLen.as<u64>(), ctx->shLenOff.as<u64>(), total + 1);
+        hipLaunchKernelGGL(k_shard_totals, dim3(1), dim3(128), 0, ctx->stream, ctx->shCntOff.as<u32>(), ctx->shLenOff.as<u64>(), n, n_ranks, ctx->shTotals.as<u64>());
+        HIP_CHECK(hipGetLastError());
+        std::vector<u64> tot((size_t)(n_ranks + 1) * 2);
+        HIP_CHECK(hipMemcpyAsync(tot.data(), ctx->shTotals.p, tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (u32 d = 0; d < n_ranks; ++d)
+        {
+            n_reads_to[d] = (u32)(tot[d + 1] - tot[d]);
+            n_bases_to[d] = tot[n_ranks + 1 + d + 1] - tot[n_ranks + 1 + d];
+        }
+        ctx->planReads = reads; ctx->planRanks = n_ranks; ctx->planTotalReads = tot[n_ranks]; ctx->planTotalBases = tot[2 * n_ranks + 1];
+    });
+}
+
+int dy_shard_pack(dy_ctx * ctx, const dy_reads * reads, void * ids_dev, void * lens_dev, void * masks_dev, void * seqs_dev)
+{
+    return guarded([&] {
+        if (!ctx || !reads) throw DyError(DY_EINVAL, "dy_shard_pack: NULL argument");
+        if (ctx->planReads != reads) throw DyError(DY_EINVAL, "dy_shard_plan must run on these reads first");
+        if (ctx->planTotalReads && (!ids_dev || !lens_dev || !masks_dev)) throw DyError(DY_EINVAL, "dy_shard_pack: NULL buffer");
+        if (ctx->planTotalBases && !seqs_dev) throw DyError(DY_EINVAL, "dy_shard_pack: NULL buffer");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 n = reads->n, W = reads->maskW;
+        const u64 total = (u64)ctx->planRanks * n;
+        if (total)
+            hipLaunchKernelGGL(k_shard_pack, dim3((u32)((total + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), reads->offs.as<u64>(), reads->seqs.as<u8>(),
+                               n, W, ctx->shOwner.as<u64>(), ctx->planRanks, ctx->shCnt.as<u32>(), ctx->shCntOff.as<u32>(), ctx->shLenOff.as<u64>(),
+                               (u32 *)ids_dev, (u32 *)lens_dev, (u64 *)masks_dev, (u8 *)seqs_dev);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
+                         uint32_t n_bins, dy_reads ** out)
+{
+    return guarded([&] {
+        if (!ctx || !out || (n_reads && (!lens_dev || !masks_dev)) || (n_bases && !seqs_dev)) throw DyError(DY_EINVAL, "dy_reads_from_device: NULL argument");
+        if (n_reads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
+        if (n_bins == 0 || n_bins > 65535) throw DyError(DY_EINVAL, "number of bins out of range");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        std::unique_ptr<dy_reads> r(new dy_reads);
+        r->ctx = ctx; r->n = n_reads; r->totalBases = n_bases;
+        r->lens.resize(n_reads);
+        if (n_reads) HIP_CHECK(hipMemcpyAsync(r->lens.data(), lens_dev, (size_t)n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+        r->seqs.reserve(n_bases + 64); r->seqsRc.reserve(n_bases + 64);
+        r->offs.reserve((size_t)(n_reads + 1) * 8);
+        const u32 W = (n_bins + 63) / 64;
+        r->masks.reserve((size_t)n_reads * W * 8 + 8);
+        r->maskW = W; r->maskBins = n_bins;
+        if (n_bases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs_dev, n_bases, hipMemcpyDeviceToDevice, ctx->stream));
+        if (n_reads) HIP_CHECK(hipMemcpyAsync(r->masks.p, masks_dev, (size_t)n_reads * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->shLen.reserve((size_t)(n_reads + 1) * 8);
+        hipLaunchKernelGGL(k_widen_lens, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)lens_dev, n_reads, ctx->shLen.as<u64>());
+        exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
+        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->planReads = nullptr;        // shLen was reused
+        u64 sum = 0; u32 mx = 0, mn = 0xFFFFFFFFu;
+        for (u32 l : r->lens) { if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded."); sum += l; mx = std::max(mx, l); mn = std::min(mn, l); }
+        if (sum != n_bases) throw DyError(DY_EINVAL, "dy_reads_from_device: lengths do not add up to n_bases");
+        r->maxLen = mx; r->minLen = n_reads ? mn : 0;
+        *out = r.release();
+    });
+}
+
+int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, uint32_t * bin_loads, uint64_t * n_raw)
+{
+    return guarded([&] {
+        if (!ctx || !idx || !reads || !p || !bin_loads || !n_raw) throw DyError(DY_EINVAL, "dy_map_bins: NULL argument");
+        if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
+        if (p->sensitivity > 1) throw DyError(DY_EUNSUPPORTED, "sensitivity 'full' (edit-distance seeds) is not implemented");
+        if (p->paired) throw DyError(DY_EUNSUPPORTED, "paired-end mapping over sharded bins is not implemented");
+        if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
+        if (reads->maskW != W || reads->maskBins != nBins) throw DyError(DY_EINVAL, "the reads carry no bin masks for this index");
+        const u32 maxErr = readErrorsOf(reads->maxLen, p->error_rate);
+        const u32 S0 = seedCountOf(maxErr, 0);
+        if (S0 > MAX_SEEDS) throw DyError(DY_EUNSUPPORTED, "more than 32 seeds per read (read length x error rate too large)");
+        ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
+        ctx->rawValid = false; ctx->lastRaw = 0;
+        for (u32 b = 0; b < nBins; ++b) bin_loads[b] = 0;
+        *n_raw = 0;
+        if (!nReads) { ctx->rawValid = true; return; }
+        // never search a bin whose FM structures are not resident
+        hipLaunchKernelGGL(k_and_masks, dim3((u32)(((u64)nReads * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), nReads, W, idx->dOwnedMask.as<u64>());
+        u32 nItems = 0, nPool = 0;
+        runSearchExtend(ctx, idx, reads, p, S0, nItems, nPool);
+        std::vector<u32> starts(nBins + 1);
+        HIP_CHECK(hipMemcpyAsync(starts.data(), ctx->binStart.p, (size_t)(nBins + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (u32 b = 0; b < nBins; ++b) bin_loads[b] = starts[b + 1] - starts[b];
+        *n_raw = nPool;
+        ctx->lastRaw = nPool; ctx->rawValid = true;
+        float ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_extend = ms;
+    });
+}
+
+int dy_raw_pack(dy_ctx * ctx, uint32_t n_ranks, const uint32_t * seg_starts, const void * ids_dev, void * raw_out_dev, uint64_t * n_raw_to)
+{
+    return guarded([&] {
+        if (!ctx || !seg_starts || !n_raw_to) throw DyError(DY_EINVAL, "dy_raw_pack: NULL argument");
+        if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
+        if (!ctx->rawValid) throw DyError(DY_EINVAL, "dy_map_bins must run first");
+        for (u32 s = 0; s < n_ranks; ++s) if (seg_starts[s + 1] < seg_starts[s]) throw DyError(DY_EINVAL, "seg_starts must be non-decreasing");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 n = ctx->lastRaw;
+        for (u32 s = 0; s < n_ranks; ++s) n_raw_to[s] = 0;
+        if (!n) return;
+        if (!ids_dev || !raw_out_dev) throw DyError(DY_EINVAL, "dy_raw_pack: NULL buffer");
+        ctx->shSeg.reserve(64 * 4 * 3 + 64);
+        u32 * segDev = ctx->shSeg.as<u32>(), * counts = segDev + 80, * cursors = segDev + 160;
+        HIP_CHECK(hipMemcpyAsync(segDev, seg_starts, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(counts, 0, 64 * 4, ctx->stream));
+        hipLaunchKernelGGL(k_raw_seg_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, counts);
+        u32 hostCounts[64];
+        HIP_CHECK(hipMemcpyAsync(hostCounts, counts, (size_t)n_ranks * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        u32 hostCursor[64]; u32 acc = 0;
+        for (u32 s = 0; s < n_ranks; ++s) { hostCursor[s] = acc; acc += hostCounts[s]; n_raw_to[s] = hostCounts[s]; }
+        if (acc != n) throw DyError(DY_EINVAL, "dy_raw_pack: seg_starts do not cover the reads of the last dy_map_bins");
+        HIP_CHECK(hipMemcpyAsync(cursors, hostCursor, (size_t)n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_raw_seg_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, (const u32 *)ids_dev, cursors,
+                           (RawMatch *)raw_out_dev);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, const void * raw_dev, uint64_t n_raw, const uint32_t * bin_loads,
+                    dy_result ** out)
+{
+    return guarded([&] {
+        if (!ctx || !idx || !reads || !p || !bin_loads || !out || (n_raw && !raw_dev)) throw DyError(DY_EINVAL, "dy_finalize_raw: NULL argument");
+        if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
+        if (p->paired) throw DyError(DY_EUNSUPPORTED, "paired-end mapping over sharded bins is not implemented");
+        if (n_raw >= 0xFFFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), nPool = (u32)n_raw;
+        const u32 maxErr = readErrorsOf(reads->maxLen, p->error_rate);
+        std::unique_ptr<dy_result> res = makeResult(ctx, reads, maxErr);
+        res->nPool = nPool;
+        if (!nReads) { *out = res.release(); return; }
+        // sortedBins() over the loads of the whole job (reference src/d_mapper.h:843-854), as k_items_bin_starts ranks them
+        std::vector<u32> rank(nBins);
+        for (u32 b = 0; b < nBins; ++b)
+        {
+            u32 r = 0;
+            for (u32 o = 0; o < nBins; ++o) if (bin_loads[o] > bin_loads[b] || (bin_loads[o] == bin_loads[b] && o < b)) ++r;
+            rank[b] = r;
+        }
+        ctx->binOrderRank.reserve((size_t)nBins * 4);
+        HIP_CHECK(hipMemcpyAsync(ctx->binOrderRank.p, rank.data(), (size_t)nBins * 4, hipMemcpyHostToDevice, st));
+        ctx->counters.reserve(64);
+        ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
+        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 32, st));
+        HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
+        HIP_CHECK(hipEventRecord(ctx->ev[5], st));
+        if (nPool)
+            hipLaunchKernelGGL(k_raw_read_counts, dim3((nPool + 255) / 256), dim3(256), 0, st, (const RawMatch *)raw_dev, nPool, nReads, ctx->readMatchCount.as<u32>(),
+                               ctx->counters.as<u32>() + 7);
+        u32 bad = 0;
+        HIP_CHECK(hipMemcpyAsync(&bad, ctx->counters.as<u32>() + 7, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (bad) throw DyError(DY_EINVAL, "dy_finalize_raw: a raw match names a read outside the batch");
+        runFinalize(ctx, idx, reads, p, res.get(), (const RawMatch *)raw_dev, nPool, 0, maxErr);
+        HIP_CHECK(hipEventRecord(ctx->ev[6], st));
+        res->readLens = reads->lens;
+        HIP_CHECK(hipStreamSynchronize(st));
+        float ms;
+        HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->stats.ms_finalize = ms;
+        ctx->stats.raw_matches = nPool;
+        *out = res.release();
+    });
 }
 
 } // extern "C"

@@ -61,7 +61,8 @@ struct HostIndex
     std::vector<u64> contigLengths;
 };
 
-inline void appendBin(HostIndex & H, const std::string & prefix)
+// withFm = false: contigs and names only (a bin whose FM structures live on another rank), BinDesc::n stays 0
+inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = true)
 {
     BinDesc d; memset(&d, 0, sizeof(d));
     MappedFile size(prefix + ".txt.size");
@@ -103,6 +104,7 @@ inline void appendBin(HostIndex & H, const std::string & prefix)
         }
     }
     // FM index
+    if (withFm)
     {
         MappedFile len(prefix + ".sa.len"), pst(prefix + ".lf.pst"), drv(prefix + ".lf.drv"), drs(prefix + ".lf.drs"),
                    drp(prefix + ".lf.drp"), ind(prefix + ".sa.ind"), val(prefix + ".sa.val");

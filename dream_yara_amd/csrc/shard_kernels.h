@@ -1,0 +1,119 @@
+// Bins sharded over ranks: device-side packing for the two exchanges of SURVEY.md §8(e).
+//   C1  reads -> owners of their selected bins   (loadFilteredReads, reference src/d_mapper.h:394-443, across ranks)
+//   C2  raw matches -> home rank of the read     (copyMatches, reference src/d_mapper.h:127-155, across ranks)
+// The library only packs and unpacks; the all-to-all itself is the caller's (RCCL over xGMI in bench.py / dist.py).
+#pragma once
+#include "dy_types.h"
+#include <hip/hip_runtime.h>
+
+namespace dy {
+
+// entry t = d * n + i : is read i wanted by rank d, and how many bases does it carry there
+__global__ void k_shard_flags(const u64 * __restrict__ masks, const u64 * __restrict__ offs, u32 n, u32 W, const u64 * __restrict__ owner, u32 nRanks,
+                              u32 * __restrict__ cnt, u64 * __restrict__ len)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = (u64)nRanks * n;
+    if (t > total) return;
+    if (t == total) { cnt[t] = 0; len[t] = 0; return; }
+    const u32 d = (u32)(t / n), i = (u32)(t % n);
+    u64 any = 0;
+    for (u32 w = 0; w < W; ++w) any |= masks[(size_t)i * W + w] & owner[(size_t)d * W + w];
+    cnt[t] = any ? 1u : 0u;
+    len[t] = any ? offs[i + 1] - offs[i] : 0;
+}
+
+__global__ void k_shard_totals(const u32 * __restrict__ cntOff, const u64 * __restrict__ lenOff, u32 n, u32 nRanks, u64 * __restrict__ out)
+{
+    const u32 d = threadIdx.x;
+    if (d > nRanks) return;
+    out[d] = cntOff[(size_t)d * n];
+    out[nRanks + 1 + d] = lenOff[(size_t)d * n];
+}
+
+// One lane per entry for the scalars; the 64 entries of a wavefront then copy their bases cooperatively.
+__global__ void k_shard_pack(const u64 * __restrict__ masks, const u64 * __restrict__ offs, const u8 * __restrict__ seqs, u32 n, u32 W,
+                             const u64 * __restrict__ owner, u32 nRanks, const u32 * __restrict__ cnt, const u32 * __restrict__ cntOff,
+                             const u64 * __restrict__ lenOff, u32 * __restrict__ outIds, u32 * __restrict__ outLens, u64 * __restrict__ outMasks,
+                             u8 * __restrict__ outSeqs)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 total = (u64)nRanks * n;
+    const u32 lane = threadIdx.x & 63;
+    bool sel = false; u32 i = 0; u64 src = 0, dst = 0; u32 L = 0;
+    if (t < total && cnt[t])
+    {
+        sel = true;
+        const u32 d = (u32)(t / n); i = (u32)(t % n);
+        const u32 pos = cntOff[t];
+        src = offs[i]; L = (u32)(offs[i + 1] - src); dst = lenOff[t];
+        outIds[pos] = i; outLens[pos] = L;
+        for (u32 w = 0; w < W; ++w) outMasks[(size_t)pos * W + w] = masks[(size_t)i * W + w] & owner[(size_t)d * W + w];
+    }
+    u64 todo = __ballot(sel);
+    while (todo)
+    {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const u64 s = __shfl(src, l, 64), dd = __shfl(dst, l, 64);
+        const u32 len = __shfl(L, l, 64);
+        for (u32 j = lane; j < len; j += 64) outSeqs[dd + j] = seqs[s + j];
+    }
+}
+
+__global__ void k_widen_lens(const u32 * __restrict__ lens, u32 n, u64 * __restrict__ out)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= n) out[t] = t < n ? lens[t] : 0;
+}
+
+__global__ void k_and_masks(u64 * __restrict__ masks, u32 n, u32 W, const u64 * __restrict__ allowed)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (u64)n * W) masks[t] &= allowed[t % W];
+}
+
+__device__ __forceinline__ u32 segmentOf(const u32 * __restrict__ segStarts, u32 nRanks, u32 read)
+{
+    u32 s = 0;
+    while (s + 1 < nRanks && read >= segStarts[s + 1]) ++s;
+    return s;
+}
+
+// raw matches per source rank (block-local histogram in LDS, one global atomic per block and rank)
+__global__ void k_raw_seg_count(const RawMatch * __restrict__ pool, u32 n, const u32 * __restrict__ segStarts, u32 nRanks, u32 * __restrict__ counts)
+{
+    __shared__ u32 local[64];
+    if (threadIdx.x < 64) local[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) atomicAdd(&local[segmentOf(segStarts, nRanks, pool[t].read)], 1u);
+    __syncthreads();
+    if (threadIdx.x < nRanks && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
+}
+
+// cursors[s] starts at the first output slot of rank s; read ids are rewritten to the ids of the home rank
+__global__ void k_raw_seg_scatter(const RawMatch * __restrict__ pool, u32 n, const u32 * __restrict__ segStarts, u32 nRanks, const u32 * __restrict__ ids,
+                                  u32 * __restrict__ cursors, RawMatch * __restrict__ out)
+{
+    __shared__ u32 local[64], base[64];
+    if (threadIdx.x < 64) local[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    RawMatch m; u32 s = 0, my = 0;
+    if (t < n) { m = pool[t]; s = segmentOf(segStarts, nRanks, m.read); my = atomicAdd(&local[s], 1u); }
+    __syncthreads();
+    if (threadIdx.x < nRanks) base[threadIdx.x] = local[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], local[threadIdx.x]) : 0;
+    __syncthreads();
+    if (t < n) { m.read = ids[m.read]; out[base[s] + my] = m; }
+}
+
+__global__ void k_raw_read_counts(const RawMatch * __restrict__ raw, u32 n, u32 nReads, u32 * __restrict__ readMatchCount, u32 * __restrict__ bad)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const u32 r = raw[t].read;
+    if (r < nReads) atomicAdd(&readMatchCount[r], 1u); else *bad = 1;
+}
+
+} // namespace dy

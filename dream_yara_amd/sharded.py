@@ -1,0 +1,101 @@
+"""Bins sharded over ranks: the harness side of include/dyhip.h's dy_shard_* / dy_map_bins /
+dy_finalize_raw.  One process per GPU; the three exchanges are torch.distributed all-to-alls on caller-owned device
+buffers (backend nccl == RCCL over xGMI; with gloo — the CPU tests and the one-GPU rehearsal — the same bytes are
+staged through the host).  The reference distributes the same unit: one child Mapper per bin, merged per read by
+copyMatches / finalizeMainMapper (reference src/d_mapper.h:127-155, 828-838, 876-884).
+
+  C0  sum(read lengths), count        all-reduce   -> the batch's one IBF threshold (src/d_mapper.h:314)
+  C1  reads -> owners of selected bins all-to-all(v) ids, lengths, masks, bases
+  C2  raw matches -> home ranks        all-to-all(v) 16 B records
+  C3  items per bin                    all-reduce   -> sortedBins() order for the CIGAR provenance rule (:843-854)
+"""
+import numpy as np
+import torch
+
+import dream_yara_amd as dy
+
+
+def bin_owner(n_bins, world):
+    """Static `bin mod G` assignment (the FM structures stay resident, so ownership cannot follow the per-batch load)."""
+    return np.arange(n_bins) % world
+
+
+def owner_masks(n_bins, world):
+    W = (n_bins + 63) // 64
+    m = np.zeros((world, W), np.uint64)
+    own = bin_owner(n_bins, world)
+    for b in range(n_bins):
+        m[own[b], b // 64] |= np.uint64(1) << np.uint64(b % 64)
+    return m
+
+
+def exchange_bytes(dist, send, send_splits, device):
+    """all-to-all(v) of a uint8 tensor split per destination rank.  Returns (recv tensor on `device`, recv splits)."""
+    world = len(send_splits)
+    backend = dist.get_backend()
+    comm_dev = device if backend == "nccl" else "cpu"
+    s = torch.tensor([int(x) for x in send_splits], dtype=torch.int64, device=comm_dev)
+    r = torch.empty(world, dtype=torch.int64, device=comm_dev)
+    dist.all_to_all_single(r, s)
+    recv_splits = [int(x) for x in r.tolist()]
+    out = torch.empty(sum(recv_splits), dtype=torch.uint8, device=comm_dev)
+    src = send if backend == "nccl" else send.cpu()
+    dist.all_to_all_single(out, src, output_split_sizes=recv_splits, input_split_sizes=[int(x) for x in send_splits])
+    return out.to(device), recv_splits
+
+
+def all_reduce_sum(dist, values, device):
+    comm_dev = device if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=comm_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return np.array(t.tolist(), dtype=np.int64)
+
+
+class ShardedMapper:
+    """One rank of a bin-sharded job: replicated filter + contigs, FM structures of `bin mod world == rank`."""
+
+    def __init__(self, ctx, dist, rank, world, index_dir, n_bins, ibf, device):
+        self.ctx, self.dist, self.rank, self.world, self.ibf, self.device = ctx, dist, rank, world, ibf, device
+        self.n_bins, self.W = n_bins, (n_bins + 63) // 64
+        self.owner_masks = owner_masks(n_bins, world)
+        self.index = dy.Index(ctx, index_dir, n_bins, owned=(bin_owner(n_bins, world) == rank).astype(np.uint8))
+
+    def threshold(self, error_rate, kmer_size, sum_len, n_reads):
+        tot = all_reduce_sum(self.dist, [sum_len, n_reads], self.device)
+        avg = int(tot[0] // max(int(tot[1]), 1))
+        return dy.threshold(error_rate, kmer_size, avg)
+
+    def map(self, reads, params, threshold):
+        """reads: this rank's dy.Reads.  Returns a dy.Result for them, equal to the single-GPU result on the whole job."""
+        ctx, dev, W = self.ctx, self.device, self.W
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        self.ibf.query(reads, threshold, want_masks=False)                          # K1
+        n_to, b_to = dy.shard_plan(ctx, reads, self.owner_masks)                    # C1 pack
+        n_tot, b_tot = int(n_to.sum()), int(b_to.sum())
+        ids, lens, masks, seqs = u8(n_tot * 4), u8(n_tot * 4), u8(n_tot * W * 8), u8(b_tot)
+        torch.cuda.synchronize()
+        dy.shard_pack(ctx, reads, ids.data_ptr(), lens.data_ptr(), masks.data_ptr(), seqs.data_ptr())
+        r_ids, rs = exchange_bytes(self.dist, ids, n_to.astype(np.int64) * 4, dev)
+        r_lens, _ = exchange_bytes(self.dist, lens, n_to.astype(np.int64) * 4, dev)
+        r_masks, _ = exchange_bytes(self.dist, masks, n_to.astype(np.int64) * W * 8, dev)
+        r_seqs, _ = exchange_bytes(self.dist, seqs, b_to.astype(np.int64), dev)
+        torch.cuda.synchronize()
+        n_recv = r_ids.numel() // 4
+        sub = dy.Reads.from_device(ctx, r_seqs.data_ptr(), r_lens.data_ptr(), r_masks.data_ptr(), n_recv, r_seqs.numel(), self.n_bins)
+        loads, n_raw = dy.map_bins(ctx, self.index, sub, params)                     # K2 + K3 on the owner
+        seg = np.zeros(self.world + 1, np.uint32); seg[1:] = np.cumsum([x // 4 for x in rs])
+        raw = u8(n_raw * dy.RAW_MATCH_BYTES)
+        torch.cuda.synchronize()
+        raw_to = dy.raw_pack(ctx, seg, r_ids.data_ptr(), raw.data_ptr())             # C2 pack
+        sub.close()
+        r_raw, _ = exchange_bytes(self.dist, raw, raw_to.astype(np.int64) * dy.RAW_MATCH_BYTES, dev)
+        g_loads = all_reduce_sum(self.dist, loads, dev)                              # C3
+        torch.cuda.synchronize()
+        self.last = {"sent_reads": n_tot, "recv_reads": n_recv, "raw_out": n_raw, "raw_in": r_raw.numel() // dy.RAW_MATCH_BYTES,
+                     "items": int(g_loads.sum())}
+        res = dy.finalize_raw(ctx, self.index, reads, params, r_raw.data_ptr(), r_raw.numel() // dy.RAW_MATCH_BYTES,
+                              g_loads.astype(np.uint32))                             # K4 on the home rank
+        return res
+
+    def close(self):
+        self.index.close()

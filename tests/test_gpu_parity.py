@@ -438,6 +438,35 @@ def test_cli_paired_end_sam_equals_oracle_cli(product_build, oracle_build, ob, t
     assert sum(1 for f in flags if f & 2) > n_pairs          # most pairs are proper
 
 
+# ---------------------------------------------------------------------------------------------- bins sharded over ranks
+@pytest.mark.parametrize("strata", [0.0, 0.02])
+def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata):
+    """two ranks (both on cuda:0, exchanges over gloo) each hold the FM structures of half the bins; the
+    merged per-read results equal the single-GPU run on the concatenated batch (which the other tests tie to the oracle)."""
+    import sys, json
+    rng = np.random.default_rng(99)
+    n_bins, k = 6, 16
+    genomes, fam = _repeat_genomes(rng, n_bins, 60000)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    ob.build_filter(str(tmp_path / "f.filter"), n_bins, 3, k, 1 << 24, np.concatenate(genomes), goffs)
+    codes, offs = _sample_reads(rng, genomes, fam, 2998, 100, 3)
+    np.savez(str(tmp_path / "reads.npz"), codes=codes, offs=offs)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29617", os.path.join(os.path.dirname(__file__), "sharded_worker.py"), str(tmp_path), str(n_bins), str(k),
+                          str(strata)], env=env, timeout=600)
+    outs = [json.load(open(tmp_path / ("out%d.json" % r))) for r in range(2)]
+    assert rc == 0, outs
+    assert all(o["bad"] == [] for o in outs)
+    assert sum(o["n"] for o in outs) == 3000 and sum(o["mapped"] for o in outs) > 2000
+    assert all(o["recv_reads"] > 0 and o["raw_in"] > 0 for o in outs)                 # both exchanges carried data
+    assert sum(o["sent_reads"] for o in outs) == sum(o["recv_reads"] for o in outs)
+    assert sum(o["raw_out"] for o in outs) == sum(o["raw_in"] for o in outs)
+
+
 # ---------------------------------------------------------------------------------------------- larger sizes: properties
 def test_error_free_reads_map_to_their_origin_at_scale(dy, ctx, product_build, tmp_path):
     from dream_yara_amd import synth
