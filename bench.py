@@ -7,8 +7,11 @@
 One step = one pass of the whole device path over one resident batch: K1 IBF sweep -> read->bin work list -> K2 seed search
 -> K3 classify/rank/locate/extend -> per-read aggregation (dedupe, strata, primary, CIGAR of primaries).  Inputs (reads,
 filter, indices) are in HBM before the timed region; results stay in HBM (the PCIe-inclusive rate is in DESIGN.md).
-Multi-GPU: reads are sharded across ranks, every rank holds the filter and all bins (1 GiB + ~1.4 GB of 288 GB), so
-there is no data-path collective; scaling is weak (1 M reads per GPU per step).
+Multi-GPU (default, --shard reads): reads are sharded across ranks, every rank holds the filter and all bins (1 GiB +
+~11 GB of 288 GB), so there is no data-path collective; scaling is weak (1 M reads per GPU per step).
+--shard bins: the reference's own unit of distribution — every rank holds the FM structures of
+`bin mod N == rank` only; reads travel to the owners of their selected bins and raw matches travel back to the read's
+home rank (two all-to-alls over RCCL, dream_yara_amd/sharded.py); same results, same weak-scaling accounting.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -85,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--shard", default="reads", choices=["reads", "bins"], help="what is partitioned across ranks (see module docstring)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -97,7 +101,7 @@ def main():
         raise SystemExit("--gpus (%d) does not match WORLD_SIZE (%d)" % (args.gpus, world))
 
     import torch
-    grp = Group("nccl" if world > 1 else None)
+    grp = Group("nccl" if (world > 1 or args.shard == "bins") else None, force=args.shard == "bins")
     rank, local_rank = grp.rank, grp.local_rank
     barrier = grp.barrier
 
@@ -118,7 +122,13 @@ def main():
     ibf = dy.Ibf.create(ctx, wl["bins"], wl["h"], wl["k"], n_bits + 256)
     for b, g in enumerate(genomes):
         ibf.add(g, b)
-    index = dy.Index(ctx, idx_dir, wl["bins"])
+    sm = None
+    if args.shard == "bins":
+        from dream_yara_amd import sharded
+        sm = sharded.ShardedMapper(ctx, grp.dist, rank, world, idx_dir, wl["bins"], ibf, "cuda")
+        index = sm.index
+    else:
+        index = dy.Index(ctx, idx_dir, wl["bins"])
     log("rank %d: filter built on device + index uploaded in %.1f s" % (rank, time.time() - t0))
 
     t0 = time.time()
@@ -132,8 +142,11 @@ def main():
     thr = dy.threshold(error_rate, wl["k"], wl["L"])
 
     def step():
-        ibf.query(reads, thr, want_masks=False)
-        res = dy.map_reads(ctx, index, reads, params, asynchronous=True)
+        if sm is not None:
+            res = sm.map(reads, params, thr)
+        else:
+            ibf.query(reads, thr, want_masks=False)
+            res = dy.map_reads(ctx, index, reads, params, asynchronous=True)
         ctx.sync()
         return res
 
@@ -185,9 +198,10 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wl["desc"], "reads_per_gpu_per_step": wl["reads"], "parallelism": "reads sharded x%d, filter+index replicated" % world,
+            "config": {"workload": wl["desc"], "reads_per_gpu_per_step": wl["reads"], "parallelism": ("reads sharded x%d, filter+index replicated" % world) if sm is None else
+                                      ("bins sharded x%d (bin mod N), filter+contigs replicated, reads->owners and raw matches->home by all-to-all" % world),
                        "mapped_fraction": mapped_fraction, "primary_in_true_bin": ok_bin,
-                       "items_per_read": stats["items"] / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
+                       "items_per_read": (stats["items"] if sm is None else sm.last["items"] / world) / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
                        "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
             "roofline": {"kernel": "k_ibf_query", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

@@ -1,20 +1,22 @@
 """Multi-GPU scaffolding of bench.py: one process per GPU (torch.distributed, backend nccl == RCCL on ROCm; gloo on CPU
-for the tests).  Reads are the sharded unit — every rank maps its own batch against the replicated filter + index — so
-the data path has no collective; only the timing protocol (barrier, max over ranks) and the result roll-up use one."""
+for the tests).  By default reads are the sharded unit — every rank maps its own batch against the replicated filter +
+index — so the data path has no collective; only the timing protocol (barrier, max over ranks) and the result roll-up
+use one.  The bin-sharded mode with its two all-to-alls lives in sharded.py."""
 import os
 
 
 class Group:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force=False):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = "cpu"
-        if self.world > 1:
+        if self.world > 1 or force:
             import torch
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
