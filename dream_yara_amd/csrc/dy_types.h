@@ -17,6 +17,7 @@ struct IbfGeom
     u64 nBits;
     u64 nHashPos;        // (bits - 256) / (64 W)
     u64 hashPosMask;     // nHashPos - 1 when nHashPos is a power of two, else 0
+    u64 hashPosMagic;    // floor(2^64 / nHashPos) for the division-free modulo (unused when hashPosMask != 0)
     u32 nBins;
     u32 nHashes;
     u32 kmerSize;

@@ -433,6 +433,7 @@ static void initGeom(IbfGeom & g, u32 bins, u32 hashes, u32 k, u64 bits)
     if (g.nHashPos == 0) throw DyError(DY_EINVAL, "IBF: filter too small for the number of bins");
     g.hashPosMask = (g.nHashPos & (g.nHashPos - 1)) == 0 ? g.nHashPos - 1 : 0;
     if (g.nHashPos == 1) g.hashPosMask = 0;
+    g.hashPosMagic = g.nHashPos ? ~0ull / g.nHashPos : 0;
     for (u32 i = 0; i < hashes; ++i) g.preCalc[i] = (u64)i ^ ((u64)k * 0x90b45d39fb6da1faull);    // :251-253
 }
 
@@ -568,16 +569,39 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         reads->maskW = W; reads->maskBins = f->g.nBins;
         if (reads->n)
         {
-            const u32 wavesPerBlock = 4;
-            size_t lds = 0;
             HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-            const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-            if (reads->maxLen < 127 + f->g.kmerSize)
-                hipLaunchKernelGGL(k_ibf_query<7>, grid, block, lds, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                   reads->n, (u32)threshold, reads->masks.as<u64>());
+            const bool longReads = reads->maxLen >= 127 + f->g.kmerSize;
+            if (W == 1 || getenv("DY_IBF_NARROW"))
+            {
+                const u32 wavesPerBlock = 4;
+                const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+                if (!longReads)
+                    hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                       reads->n, (u32)threshold, reads->masks.as<u64>());
+                else
+                    hipLaunchKernelGGL(k_ibf_query<14>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                       reads->n, (u32)threshold, reads->masks.as<u64>());
+            }
             else
-                hipLaunchKernelGGL(k_ibf_query<14>, grid, block, lds, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                   reads->n, (u32)threshold, reads->masks.as<u64>());
+            {   // G = lanes per k-mer; LDS per wave = 64 hashes + the hash-0 words of as many k-mers as fit in ~19 KB
+                u32 gShift = 1;
+                while ((1u << gShift) < W && gShift < 4) ++gShift;
+                const u32 G = 1u << gShift;
+                const u32 nK = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
+                const u32 cacheKmers = std::min<u32>(nK, (19 * 1024 - 512) / (G * 8));
+                const size_t perWave = (64 + (size_t)cacheKmers * G) * 8;
+                const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
+                const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+                if (nK <= 127)
+                    hipLaunchKernelGGL(k_ibf_query_wide<7>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
+                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers);
+                else if (nK <= 255)
+                    hipLaunchKernelGGL(k_ibf_query_wide<8>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
+                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers);
+                else
+                    hipLaunchKernelGGL(k_ibf_query_wide<14>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
+                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers);
+            }
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
         }

@@ -43,7 +43,13 @@ __device__ __forceinline__ u64 ibfWordIndex(const IbfGeom & g, u64 kmerHash, u32
 {
     u64 v = g.preCalc[i] * kmerHash;
     v ^= v >> 27;
-    v = g.hashPosMask ? (v & g.hashPosMask) : (v % g.nHashPos);
+    if (g.hashPosMask) v &= g.hashPosMask;
+    else
+    {   // v % nHashPos without a 64-bit division: hashPosMagic = floor(2^64 / nHashPos), so the quotient estimate is at most 2 short
+        const u64 q = __umul64hi(v, g.hashPosMagic);
+        v -= q * g.nHashPos;
+        while (v >= g.nHashPos) v -= g.nHashPos;
+    }
     return v * g.W;
 }
 
@@ -240,6 +246,170 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
             }
         }
         if (lane == 0) out[w] = selW;
+    }
+}
+
+// ---- K1 for filters with more than 64 bins (W >= 2 words per hash position) ------------------------------------------
+// A hash position is W consecutive words (32 B at 256 bins, 128 B at 1024 bins), so G = min(pow2 >= W, 16) adjacent lanes
+// serve one k-mer and a sub-pass of the wave covers 64/G k-mers with fully used 32..128-byte requests; every lane keeps
+// its own bit-sliced counters (one word of one k-mer slot) and the 64/G slots are summed by a butterfly once per phase.
+//   phase A  hash function 0 for every k-mer; the words are kept in LDS.  Upper bounds -> candidate bins.
+//   phase B  one sweep over the k-mers with lazy gathers: a lane fetches hash function 1.. only while its word still
+//            carries a candidate bit; exact counts; the sweep stops once every candidate is decided.
+// Filters with more than 16 words are handled 16 words at a time (the words of a position are independent).
+__device__ __forceinline__ u64 shflXor64(u64 v, int d)
+{
+    return ((u64)__shfl_xor((u32)(v >> 32), d, 64) << 32) | __shfl_xor((u32)v, d, 64);
+}
+// planes += m (a one-bit number per bin)
+template <int NP>
+__device__ __forceinline__ void planesAddBit(u64 (&planes)[NP], u64 m)
+{
+    u64 carry = m;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { const u64 t = planes[p] & carry; planes[p] ^= carry; carry = t; }
+}
+// sum of the per-lane counters over the lanes that differ in bits >= log2(G): every lane ends with its word's total
+template <int NP>
+__device__ __forceinline__ void planesReduceSlots(u64 (&planes)[NP], u32 G)
+{
+    for (u32 d = G; d < 64; d <<= 1)
+    {
+        u64 carry = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+            const u64 o = shflXor64(planes[p], (int)d);
+            const u64 x = planes[p] ^ o;
+            const u64 sum = x ^ carry;
+            carry = (planes[p] & o) | (carry & x);
+            planes[p] = sum;
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__ words, IbfGeom g,
+                                                        const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
+                                                        u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 cacheKmers)
+{
+    extern __shared__ u64 ldsWide[];
+    constexpr u32 U = 4;            // sub-passes whose gathers are in flight together
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (read >= nReads) return;
+    const u8 * seq = seqs + offs[read];
+    const u32 len = (u32)(offs[read + 1] - offs[read]);
+    const u32 k = g.kmerSize;
+    u64 * out = masks + (size_t)read * g.W;
+    if (len < k || threshold == 0)
+    {
+        for (u32 w = lane; w < g.W; w += 64)
+        {
+            const u32 left = g.nBins - w * 64;
+            out[w] = threshold == 0 ? (left >= 64 ? ~0ull : ((1ull << left) - 1)) : 0ull;
+        }
+        return;
+    }
+    const u32 nKmers = len - k + 1;
+    const u64 kMask = (1ull << k) - 1;
+    const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
+    u64 * myHash = ldsWide + (size_t)wave * (64 + (size_t)cacheKmers * G);       // hashes of the current chunk of 64 k-mers
+    u64 * myW0 = myHash + 64;                                                     // hash-0 words of the first cacheKmers k-mers
+
+    for (u32 w0 = 0; w0 < g.W; w0 += G)
+    {
+        const u32 w = w0 + wl;
+        const bool wOk = w < g.W;
+        const u32 left = wOk ? g.nBins - w * 64 : 0;
+        const u64 binMask = left >= 64 ? ~0ull : ((1ull << left) - 1);
+        u64 selW = 0;
+        for (u32 strand = 0; strand < 2; ++strand)
+        {
+            const bool firstIsN = strandCode(seq, len, 0, strand) > 3;
+            // ---- phase A
+            u64 planes[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) planes[p] = 0;
+            for (u32 base = 0; base < nKmers; base += 64)
+            {
+                __builtin_amdgcn_wave_barrier();
+                myHash[lane] = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
+                __builtin_amdgcn_wave_barrier();
+                const u32 inChunk = min(64u, nKmers - base);
+                for (u32 s0 = 0; s0 * slots < inChunk; s0 += U)
+                {
+                    u64 m[U];
+#pragma unroll
+                    for (u32 u = 0; u < U; ++u)
+                    {
+                        const u32 kl = ((s0 + u) * slots + slot) & 63;
+                        const bool valid = (s0 + u) * slots + slot < inChunk && wOk;
+                        m[u] = valid ? words[ibfWordIndex(g, myHash[kl], 0) + w] : 0;
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < U; ++u)
+                    {
+                        const u32 kk = base + (s0 + u) * slots + slot;
+                        if ((s0 + u) * slots < 64 && kk < cacheKmers) myW0[(size_t)kk * G + wl] = m[u];
+                        planesAddBit(planes, m[u]);
+                    }
+                }
+            }
+            planesReduceSlots(planes, G);
+            const u64 cand = planesGe(planes, (int)threshold) & binMask;
+            if (ballot64(cand != 0) == 0) continue;
+            // ---- phase B
+#pragma unroll
+            for (int p = 0; p < NP; ++p) planes[p] = 0;
+            u32 nextCheck = threshold + threshold / 4;
+            bool done = false;
+            for (u32 base = 0; base < nKmers && !done; base += 64)
+            {
+                __builtin_amdgcn_wave_barrier();
+                myHash[lane] = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
+                __builtin_amdgcn_wave_barrier();
+                const u32 inChunk = min(64u, nKmers - base);
+                for (u32 s0 = 0; s0 * slots < inChunk; s0 += U)
+                {
+                    u64 c[U], hk[U];
+#pragma unroll
+                    for (u32 u = 0; u < U; ++u)
+                    {
+                        const u32 kl = ((s0 + u) * slots + slot) & 63;
+                        const u32 kk = base + (s0 + u) * slots + slot;
+                        const bool valid = (s0 + u) * slots + slot < inChunk && cand != 0;
+                        hk[u] = myHash[kl];
+                        c[u] = 0;
+                        if (valid) c[u] = (kk < cacheKmers ? myW0[(size_t)kk * G + wl] : words[ibfWordIndex(g, hk[u], 0) + w]) & cand;
+                    }
+                    for (u32 hf = 1; hf < g.nHashes; ++hf)
+                    {
+                        u64 v[U];
+#pragma unroll
+                        for (u32 u = 0; u < U; ++u) v[u] = c[u] ? words[ibfWordIndex(g, hk[u], hf) + w] : 0;
+#pragma unroll
+                        for (u32 u = 0; u < U; ++u) c[u] &= v[u];
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < U; ++u) planesAddBit(planes, c[u]);
+                    const u32 processed = min(nKmers, base + min(64u, (s0 + U) * slots));
+                    if (processed >= nextCheck && processed < nKmers)
+                    {   // every candidate decided?  exact so far >= threshold, or out of reach even if all remaining k-mers hit
+                        u64 e[NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) e[p] = planes[p];
+                        planesReduceSlots(e, G);
+                        const u64 open = cand & ~planesGe(e, (int)threshold) & planesGe(e, (int)threshold - (int)(nKmers - processed));
+                        if (ballot64(open != 0) == 0) { done = true; break; }
+                        nextCheck = processed + max(threshold / 2, 32u);
+                    }
+                }
+            }
+            planesReduceSlots(planes, G);
+            selW |= planesGe(planes, (int)threshold) & cand;
+        }
+        if (slot == 0 && wOk) out[w] = selW;
     }
 }
 
