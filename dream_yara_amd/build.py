@@ -42,7 +42,8 @@ def build(force=False):
     srcs = _sources()
     lib_srcs = [s for s in srcs if not s.endswith(".cpp")]   # headers, .hip and this build script
     if force or not _newer(LIB, lib_srcs):
-        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", LIB,
+        extra = os.environ.get("DY_HIPCC_FLAGS", "").split()       # tuning experiments only (e.g. -DDY_K3_WAVES=6)
+        _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"] + extra + ["-o", LIB,
               os.path.join(CSRC, "dyhip.hip")])
     for tool in ("dream_yara_mapper", "dream_yara_build_filter", "dream_yara_indexer"):
         src = os.path.join(CSRC, tool + ".cpp")

@@ -81,7 +81,7 @@ struct dy_ctx
     DevBuf peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg;
+           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList;
     size_t poolCap = 0;
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
@@ -161,7 +161,10 @@ template <int NW>
 static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink)
 {
     hipLaunchKernelGGL(k_extend<NW>, dim3(((nItems + 255) / 256 + 7) / 8 * 8), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
-                       nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2);
+                       nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>());
+    // re-seeded items: list-driven, spread thinly over a full grid (normally a tiny fraction of the items)
+    hipLaunchKernelGGL(k_extend_hard<NW>, dim3(2048), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(),
+                       ctx->itemBin.as<u16>(), S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>());
 }
 
 // Work list + K2 + K3: (read,bin) items of the masks on `reads` -> raw matches in ctx->pool, per-read counts in ctx->readMatchCount.
@@ -212,6 +215,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         // ---- K3: classify, rank, locate, extend -> raw match pool (grown and re-run on overflow)
         ctx->counters.reserve(64);
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
+        ctx->hardList.reserve((size_t)nItems * 4 + 64);
         if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
         u32 hostCounters[4] = {0, 0, 0, 0};     // [0] pool count, [1] overflow flag, [2] hard items
         const int nw = (int)((reads->maxLen + 63) / 64);
@@ -588,8 +592,8 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 while ((1u << gShift) < W && gShift < 4) ++gShift;
                 const u32 G = 1u << gShift;
                 const u32 nK = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
-                const u32 cacheKmers = std::min<u32>(nK, (19 * 1024 - 512) / (G * 8));
-                const size_t perWave = (64 + (size_t)cacheKmers * G) * 8;
+                const u32 cacheKmers = std::min<u32>(nK, (19 * 1024 - 1024) / (G * 8));
+                const size_t perWave = (128 + (size_t)cacheKmers * G) * 8;
                 const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
                 if (nK <= 127)

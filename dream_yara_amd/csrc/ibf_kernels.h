@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
                                                         u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 cacheKmers)
 {
     extern __shared__ u64 ldsWide[];
-    constexpr u32 U = 4;            // sub-passes whose gathers are in flight together
+    constexpr u32 UA = 8, UB = 4;   // sub-passes whose gathers are in flight together (phase A / phase B)
+    constexpr u32 CH = 128;         // k-mers hashed per outer iteration (two ballots' worth)
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
     if (read >= nReads) return;
@@ -314,8 +315,8 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
     const u32 nKmers = len - k + 1;
     const u64 kMask = (1ull << k) - 1;
     const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
-    u64 * myHash = ldsWide + (size_t)wave * (64 + (size_t)cacheKmers * G);       // hashes of the current chunk of 64 k-mers
-    u64 * myW0 = myHash + 64;                                                     // hash-0 words of the first cacheKmers k-mers
+    u64 * myHash = ldsWide + (size_t)wave * (CH + (size_t)cacheKmers * G);       // hashes of the current CH k-mers
+    u64 * myW0 = myHash + CH;                                                     // hash-0 words of the first cacheKmers k-mers
 
     for (u32 w0 = 0; w0 < g.W; w0 += G)
     {
@@ -331,69 +332,87 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
             u64 planes[NP];
 #pragma unroll
             for (int p = 0; p < NP; ++p) planes[p] = 0;
-            for (u32 base = 0; base < nKmers; base += 64)
+            for (u32 base = 0; base < nKmers; base += CH)
             {
                 __builtin_amdgcn_wave_barrier();
                 myHash[lane] = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
+                if (base + 64 < nKmers) myHash[64 + lane] = laneKmerHash(seq, len, strand, base + 64, lane, k, kMask, firstIsN);
                 __builtin_amdgcn_wave_barrier();
-                const u32 inChunk = min(64u, nKmers - base);
-                for (u32 s0 = 0; s0 * slots < inChunk; s0 += U)
+                const u32 inChunk = min(CH, nKmers - base);
+                for (u32 s0 = 0; s0 * slots < inChunk; s0 += UA)
                 {
-                    u64 m[U];
+                    u64 m[UA];
 #pragma unroll
-                    for (u32 u = 0; u < U; ++u)
+                    for (u32 u = 0; u < UA; ++u)
                     {
-                        const u32 kl = ((s0 + u) * slots + slot) & 63;
-                        const bool valid = (s0 + u) * slots + slot < inChunk && wOk;
-                        m[u] = valid ? words[ibfWordIndex(g, myHash[kl], 0) + w] : 0;
+                        const u32 kl = (s0 + u) * slots + slot;
+                        const bool valid = kl < inChunk && wOk;
+                        m[u] = valid ? words[ibfWordIndex(g, myHash[kl & (CH - 1)], 0) + w] : 0;
                     }
 #pragma unroll
-                    for (u32 u = 0; u < U; ++u)
+                    for (u32 u = 0; u < UA; ++u)
                     {
-                        const u32 kk = base + (s0 + u) * slots + slot;
-                        if ((s0 + u) * slots < 64 && kk < cacheKmers) myW0[(size_t)kk * G + wl] = m[u];
+                        const u32 kl = (s0 + u) * slots + slot;
+                        if (kl < inChunk && base + kl < cacheKmers) myW0[(size_t)(base + kl) * G + wl] = m[u];
                         planesAddBit(planes, m[u]);
                     }
                 }
             }
             planesReduceSlots(planes, G);
             const u64 cand = planesGe(planes, (int)threshold) & binMask;
-            if (ballot64(cand != 0) == 0) continue;
+            const u64 candLanes = ballot64(cand != 0);
+            if (candLanes == 0) continue;
+            // few candidate words: fetch the remaining hash functions together; many (low thresholds): one after the other, lazily
+            const bool eager = __popcll(candLanes) <= (int)(2 * slots);
             // ---- phase B
 #pragma unroll
             for (int p = 0; p < NP; ++p) planes[p] = 0;
             u32 nextCheck = threshold + threshold / 4;
             bool done = false;
-            for (u32 base = 0; base < nKmers && !done; base += 64)
+            for (u32 base = 0; base < nKmers && !done; base += CH)
             {
                 __builtin_amdgcn_wave_barrier();
                 myHash[lane] = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
+                if (base + 64 < nKmers) myHash[64 + lane] = laneKmerHash(seq, len, strand, base + 64, lane, k, kMask, firstIsN);
                 __builtin_amdgcn_wave_barrier();
-                const u32 inChunk = min(64u, nKmers - base);
-                for (u32 s0 = 0; s0 * slots < inChunk; s0 += U)
+                const u32 inChunk = min(CH, nKmers - base);
+                for (u32 s0 = 0; s0 * slots < inChunk; s0 += UB)
                 {
-                    u64 c[U], hk[U];
+                    u64 c[UB], hk[UB];
 #pragma unroll
-                    for (u32 u = 0; u < U; ++u)
+                    for (u32 u = 0; u < UB; ++u)
                     {
-                        const u32 kl = ((s0 + u) * slots + slot) & 63;
-                        const u32 kk = base + (s0 + u) * slots + slot;
-                        const bool valid = (s0 + u) * slots + slot < inChunk && cand != 0;
-                        hk[u] = myHash[kl];
+                        const u32 kl = (s0 + u) * slots + slot;
+                        const u32 kk = base + kl;
+                        const bool valid = kl < inChunk && cand != 0;
+                        hk[u] = myHash[kl & (CH - 1)];
                         c[u] = 0;
                         if (valid) c[u] = (kk < cacheKmers ? myW0[(size_t)kk * G + wl] : words[ibfWordIndex(g, hk[u], 0) + w]) & cand;
                     }
-                    for (u32 hf = 1; hf < g.nHashes; ++hf)
+                    if (eager && g.nHashes == 3)
                     {
-                        u64 v[U];
+                        u64 v1[UB], v2[UB];
 #pragma unroll
-                        for (u32 u = 0; u < U; ++u) v[u] = c[u] ? words[ibfWordIndex(g, hk[u], hf) + w] : 0;
+                        for (u32 u = 0; u < UB; ++u)
+                        {
+                            v1[u] = c[u] ? words[ibfWordIndex(g, hk[u], 1) + w] : 0;
+                            v2[u] = c[u] ? words[ibfWordIndex(g, hk[u], 2) + w] : 0;
+                        }
 #pragma unroll
-                        for (u32 u = 0; u < U; ++u) c[u] &= v[u];
+                        for (u32 u = 0; u < UB; ++u) c[u] &= v1[u] & v2[u];
                     }
+                    else
+                        for (u32 hf = 1; hf < g.nHashes; ++hf)
+                        {
+                            u64 v[UB];
 #pragma unroll
-                    for (u32 u = 0; u < U; ++u) planesAddBit(planes, c[u]);
-                    const u32 processed = min(nKmers, base + min(64u, (s0 + U) * slots));
+                            for (u32 u = 0; u < UB; ++u) v[u] = c[u] ? words[ibfWordIndex(g, hk[u], hf) + w] : 0;
+#pragma unroll
+                            for (u32 u = 0; u < UB; ++u) c[u] &= v[u];
+                        }
+#pragma unroll
+                    for (u32 u = 0; u < UB; ++u) planesAddBit(planes, c[u]);
+                    const u32 processed = min(nKmers, base + min(CH, (s0 + UB) * slots));
                     if (processed >= nextCheck && processed < nKmers)
                     {   // every candidate decided?  exact so far >= threshold, or out of reach even if all remaining k-mers hit
                         u64 e[NP];

@@ -451,9 +451,23 @@ __device__ void fmBacktrack(const BinView & b, const u8 * __restrict__ seq, u32 
 // ---------------------------------------------------------------------------------------------------
 // K3: one thread per work item runs the read-local remainder of _mapReadsImpl.
 // ---------------------------------------------------------------------------------------------------
+// classifyReads for one item (reference src/mapper_classifier.h:111-155): 0 = easy, 1 / 2 = re-seed with that many seed errors
+__device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S0, const MapParams & prm)
+{
+    u64 total = 0;
+    for (u32 s = 0; s < 2 * S0; ++s) total += h0[s].y - h0[s].x;
+    if (total > prm.hitsThreshold) return (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
+    return 0;
+}
+
+// Easy items (seedErrors == 0): rankSeeds + extendHits<0>(bucket 0) for the whole wavefront.
+// Every lane walks its own (rank, strand, SA row) sequence — seeds by ascending hit count, ties keep ascending seed
+// id, forward hits before reverse hits, early exit after a rank — but the lanes meet at ONE extension call per
+// round, so the wavefront pays for max(#occurrences per lane) extensions instead of one per (rank, strand) pair.
 template <int NW>
-__device__ void extendItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
-                           const uint2 * __restrict__ hits0, const MatchSink & sink, u32 * __restrict__ hardItems, ItemState & st, bool valid)
+__device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
+                               const uint2 * __restrict__ hits0, const MatchSink & sink, u32 * __restrict__ hardCount, u32 * __restrict__ hardList,
+                               ItemState & st, bool valid)
 {
     const u8 * seq = nullptr, * seqRc = nullptr;
     u32 len = 0, readErrors = 0, readStrata = 0, cnt0 = 1, seedErrors = 0;
@@ -467,67 +481,67 @@ __device__ void extendItem(const IndexView & ix, const ReadsView & rd, u32 item,
         readErrors = readErrorsOf(len, prm.errorRate); readStrata = readStrataOf(len, prm.strataRate);
         b = makeBinView(ix, bin);
         h0 = hits0 + (size_t)item * 2 * S0;
-        // ---- classifyReads (reference src/mapper_classifier.h:111-155)
         cnt0 = seedCountOf(readErrors, 0);
-        u64 total = 0;
-        for (u32 s = 0; s < 2 * S0; ++s) total += h0[s].y - h0[s].x;
-        if (total > prm.hitsThreshold) seedErrors = (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
+        seedErrors = classifyItem(h0, S0, prm);
+        if (seedErrors) hardList[atomicAdd(hardCount, 1u)] = item;          // left to k_extend_hard
     }
-
-    // ---- rankSeeds + extendHits<0>(bucket 0) for the easy reads of the whole wavefront.
-    // Every lane walks its own (rank, strand, SA row) sequence — seeds by ascending hit count, ties keep ascending seed
-    // id, forward hits before reverse hits, early exit after a rank — but the lanes meet at ONE extension call per
-    // round, so the wavefront pays for max(#occurrences per lane) extensions instead of one per (rank, strand) pair.
-    {
-        bool active = valid && seedErrors == 0 && len >= cnt0;
-        const u32 seedLen = active ? len / cnt0 : 0;
-        u32 done[2] = {0, 0};   // bitmask of seeds already taken per strand (cnt0 <= 32)
-        u32 rank = 0, strand = 0, row = 0, rowEnd = 0, needleBegin = 0;
-        auto pickSeed = [&]() {
-            u32 best = 0xFFFFFFFFu, bestId = 0;
-            for (u32 k = 0; k < cnt0; ++k)
-            {
-                if (done[strand] >> k & 1) continue;
-                const uint2 r = h0[strand * S0 + k];
-                const u32 c = r.y - r.x;
-                if (c < best) { best = c; bestId = k; }
-            }
-            done[strand] |= 1u << bestId;
-            const uint2 r = h0[strand * S0 + bestId];
-            row = r.x; rowEnd = r.y; needleBegin = (cnt0 - 1 - bestId) * seedLen;
-        };
-        if (active) pickSeed();
-        for (;;)
+    bool active = valid && seedErrors == 0 && len >= cnt0;
+    const u32 seedLen = active ? len / cnt0 : 0;
+    u32 done[2] = {0, 0};   // bitmask of seeds already taken per strand (cnt0 <= 32)
+    u32 rank = 0, strand = 0, row = 0, rowEnd = 0, needleBegin = 0;
+    auto pickSeed = [&]() {
+        u32 best = 0xFFFFFFFFu, bestId = 0;
+        for (u32 k = 0; k < cnt0; ++k)
         {
-            bool have = false;
-            while (active)
-            {
-                if (row < rowEnd) { have = true; break; }
-                if (strand == 0) { strand = 1; pickSeed(); }
-                else
-                {
-                    if (st.minErrors + readStrata <= rank) { st.mapped = true; active = false; break; }   // seedErrors = 0: rank * (0 + 1)
-                    if (++rank >= cnt0) { active = false; break; }
-                    strand = 0; pickSeed();
-                }
-            }
-            if (!__ballot(have)) break;
-            if (have && !(sink.debugFlags & 2))
-            {   // _extendHitImpl for one SA row (reference src/mapper_extender.h:263-285)
-                u32 contig, x;
-                fmLocate(b, row, contig, x);
-                ++row;
-                const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
-                if (clen - x >= seedLen && !(sink.debugFlags & 1))
-                    extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
-            }
-            else if (have) ++row;
+            if (done[strand] >> k & 1) continue;
+            const uint2 r = h0[strand * S0 + k];
+            const u32 c = r.y - r.x;
+            if (c < best) { best = c; bestId = k; }
         }
+        done[strand] |= 1u << bestId;
+        const uint2 r = h0[strand * S0 + bestId];
+        row = r.x; rowEnd = r.y; needleBegin = (cnt0 - 1 - bestId) * seedLen;
+    };
+    if (active) pickSeed();
+    for (;;)
+    {
+        bool have = false;
+        while (active)
+        {
+            if (row < rowEnd) { have = true; break; }
+            if (strand == 0) { strand = 1; pickSeed(); }
+            else
+            {
+                if (st.minErrors + readStrata <= rank) { st.mapped = true; active = false; break; }   // seedErrors = 0: rank * (0 + 1)
+                if (++rank >= cnt0) { active = false; break; }
+                strand = 0; pickSeed();
+            }
+        }
+        if (!__ballot(have)) break;
+        if (have && !(sink.debugFlags & 2))
+        {   // _extendHitImpl for one SA row (reference src/mapper_extender.h:263-285)
+            u32 contig, x;
+            fmLocate(b, row, contig, x);
+            ++row;
+            const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+            if (clen - x >= seedLen && !(sink.debugFlags & 1))
+                extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
+        }
+        else if (have) ++row;
     }
-    if (!valid || seedErrors == 0) return;
+}
 
-    // ---- hard read: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2)
-    atomicAdd(hardItems, 1u);
+// Hard item: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2), Hamming backtracking in the FM index.
+template <int NW>
+__device__ void extendHardItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
+                               const uint2 * __restrict__ hits0, const MatchSink & sink, ItemState & st)
+{
+    const u8 * seq = rd.seqs + rd.offs[read];
+    const u8 * seqRc = rd.seqsRc + rd.offs[read];
+    const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
+    const u32 readErrors = readErrorsOf(len, prm.errorRate), readStrata = readStrataOf(len, prm.strataRate);
+    const BinView b = makeBinView(ix, bin);
+    const u32 seedErrors = classifyItem(hits0 + (size_t)item * 2 * S0, S0, prm);
     const u32 cntB = seedCountOf(readErrors, seedErrors);
     if (len < cntB) return;
     const u32 seedLen = len / cntB;
@@ -567,20 +581,13 @@ __device__ void extendItem(const IndexView & ix, const ReadsView & rd, u32 item,
     }
 }
 
-template <int NW>
-__global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
-                                                u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
-                                                u32 * __restrict__ hardItems)
+#ifndef DY_K3_WAVES
+#define DY_K3_WAVES 4      // waves per SIMD the easy-path kernel is compiled for at NW <= 2 (measured: 4 -> 1.10 ms, 5 -> 1.11 ms, 6 -> 1.20 ms: spills eat the gain)
+#endif
+
+// one pool reservation per wavefront for the matches buffered in the lanes' ItemStates
+__device__ __forceinline__ void flushWaveMatches(const ItemState & st, u32 read, const MatchSink & sink, u32 lane)
 {
-    const u32 item = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    const u32 lane = threadIdx.x & 63;
-    ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
-    u32 read = 0;
-    u32 bin = 0;
-    const bool valid = item < nItems;
-    if (valid) { read = itemRead[item]; bin = itemBin[item]; }
-    extendItem<NW>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardItems, st, valid);
-    // one reservation per wavefront for the buffered matches
     const u32 cnt = st.nbuf;
     u32 incl = cnt;
 #pragma unroll
@@ -598,6 +605,49 @@ __global__ __launch_bounds__(256) void k_extend(IndexView ix, ReadsView rd, cons
     if (cnt >= 2)
     {
         if (first + 1 < sink.poolCap) { sink.pool[first + 1] = st.buf1; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? DY_K3_WAVES : 1, NW <= 2 ? DY_K3_WAVES : 8))) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
+                                                u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
+                                                u32 * __restrict__ hardCount, u32 * __restrict__ hardList)
+{
+    const u32 item = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
+    ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
+    u32 read = 0;
+    u32 bin = 0;
+    const bool valid = item < nItems;
+    if (valid) { read = itemRead[item]; bin = itemBin[item]; }
+    extendEasyItem<NW>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardCount, hardList, st, valid);
+    flushWaveMatches(st, read, sink, lane);
+}
+
+// The re-seeded items listed by k_extend (the list length is only known on the device).
+template <int NW>
+__global__ __launch_bounds__(256) void k_extend_hard(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
+                                                     u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
+                                                     const u32 * __restrict__ hardCount, const u32 * __restrict__ hardList)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 n = *hardCount;
+    // Hard items diverge (backtracking depth, hit counts), and a wavefront runs as long as the sum of its lanes' distinct
+    // paths: spread the list over all waves of the grid, as few items per wave as the list length allows.
+    const u32 totalWaves = gridDim.x * (blockDim.x >> 6), waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u32 perWave = min(64u, (n + totalWaves - 1) / totalWaves);
+    for (u32 first = waveId * perWave; first < n; first += totalWaves * perWave)
+    {
+        const u32 i = first + lane;
+        ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
+        u32 read = 0;
+        if (lane < perWave && i < n)
+        {
+            const u32 item = hardList[i];
+            read = itemRead[item];
+            extendHardItem<NW>(ix, rd, item, read, itemBin[item], S0, prm, hits0, sink, st);
+        }
+        flushWaveMatches(st, read, sink, lane);
     }
 }
 
