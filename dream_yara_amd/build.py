@@ -52,6 +52,8 @@ def build(force=False):
             continue
         if force or not _newer(exe, [src, LIB] + [s for s in srcs if s.endswith((".h", ".hpp"))]):
             link = [] if tool == "dream_yara_indexer" else ["-L" + CSRC, "-ldyhip", "-Wl,-rpath,$ORIGIN"]
+            if tool == "dream_yara_mapper":
+                link = ["-DDY_HAVE_ZLIB"] + link + ["-lz"]          # BAM output, gzip input
             _run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, src] + link)
     return LIB
 

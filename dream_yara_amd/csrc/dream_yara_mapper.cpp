@@ -3,6 +3,7 @@
 // Host work here is I/O only: option parsing, FASTA/FASTQ batches in, SAM text out (reference src/mapper_writer.h).
 #include "../../include/dyhip.h"
 #include "host_formats.hpp"
+#include "bam_writer.hpp"
 #include <iostream>
 #include <fstream>
 #include <sstream>
@@ -110,17 +111,25 @@ int main(int argc, char ** argv)
         dy_index * idx = nullptr; check(dy_index_load(ctx, opt.indicesDir.c_str(), nBins, &idx));
         auto t1 = std::chrono::steady_clock::now();
 
+        // output format by extension (reference src/d_mapper.cpp:140-153): .bam -> BGZF-compressed BAM, anything else -> SAM text
+        const bool bam = opt.outputFile.size() >= 4 && opt.outputFile.compare(opt.outputFile.size() - 4, 4, ".bam") == 0;
         std::ofstream ofs;
-        if (!opt.outputFile.empty()) { ofs.open(opt.outputFile); if (!ofs) fail("Error while opening output file."); }
+        if (!opt.outputFile.empty()) { ofs.open(opt.outputFile, bam ? std::ios::binary : std::ios::out); if (!ofs) fail("Error while opening output file."); }
         std::ostream & os = opt.outputFile.empty() ? std::cout : ofs;
+        std::vector<std::string> contigNames; std::vector<uint64_t> contigLengths;
+        for (uint32_t c = 0; c < dy_index_contigs(idx); ++c) { contigNames.push_back(dy_index_contig_name(idx, c)); contigLengths.push_back(dy_index_contig_length(idx, c)); }
+        std::string headerText;
         if (!opt.skipSamHeader)
         {   // fillHeader, reference src/mapper_writer.h:124-155; order as in the gold files
-            os << "@HD\tVN:1.4\tSO:unsorted\n";
-            os << "@PG\tID:Yara\tPN:Yara\tVN:1.0.2 []\tCL:" << opt.commandLine << "\n";
-            os << "@RG\tID:" << opt.readGroup << "\tSM:" << opt.readGroup << "\tPG:Yara\n";
-            for (uint32_t c = 0; c < dy_index_contigs(idx); ++c)
-                os << "@SQ\tSN:" << dy_index_contig_name(idx, c) << "\tLN:" << dy_index_contig_length(idx, c) << "\n";
+            headerText += "@HD\tVN:1.4\tSO:unsorted\n";
+            headerText += "@PG\tID:Yara\tPN:Yara\tVN:1.0.2 []\tCL:" + opt.commandLine + "\n";
+            headerText += "@RG\tID:" + opt.readGroup + "\tSM:" + opt.readGroup + "\tPG:Yara\n";
+            for (size_t c = 0; c < contigNames.size(); ++c) headerText += "@SQ\tSN:" + contigNames[c] + "\tLN:" + std::to_string(contigLengths[c]) + "\n";
         }
+        BgzfWriter bgzf(os);
+        std::vector<uint8_t> bamScratch;
+        if (bam) bamWriteHeader(bgzf, headerText, contigNames, contigLengths);
+        else os << headerText;
 
         ReadsFile in(opt.readsFile);
         std::unique_ptr<ReadsFile> in2;
@@ -161,102 +170,72 @@ int main(int argc, char ** argv)
             const dy_read_result * rr = dy_result_reads(res);
             const dy_match * ms = dy_result_matches(res);
             const uint32_t * cg = dy_result_cigars(res);
-            // ---- SAM records (reference src/mapper_writer.h:296-345, 593-634)
+            // ---- alignment records (reference src/mapper_writer.h:296-345, 593-634; pairs :268-293,347-400,515-571)
             for (size_t i = 0; i < batch.size(); ++i)
             {
                 const dy_read_result & r = rr[i];
-                rec.clear();
+                AlnRecord a;
                 const std::string & name = batch.names[i];
                 size_t cut = name.find_first_of(" \t/");
-                rec.append(name, 0, cut == std::string::npos ? name.size() : cut);
+                a.qname.assign(name, 0, cut == std::string::npos ? name.size() : cut);
                 const u8 * codes = batch.codes.data() + batch.offs[i];
                 const char * quals = batch.quals.data() + batch.offs[i];
                 const size_t len = (size_t)(batch.offs[i + 1] - batch.offs[i]);
                 const bool rev = r.mapped && r.primary.is_rev;
+                if (r.mapped)
+                {
+                    a.rid = (int32_t)r.primary.contig; a.pos = (int32_t)r.primary.begin; a.mapq = r.mapq;
+                    a.cigar = cg + r.cigar_begin; a.nCigar = r.cigar_len;
+                    if (rev) a.flag |= 16;
+                }
+                else a.flag |= 4;
                 if (opt.params.paired)
-                {   // _writeMappedRead / _writeUnmappedRead for pairs (reference src/mapper_writer.h:268-293,347-400,515-571)
+                {
                     const dy_read_result & mr = rr[i < nPairs ? i + nPairs : i - nPairs];
-                    unsigned flag = 1u | (i < nPairs ? 64u : 128u);
-                    if (!mr.mapped) flag |= 8;
-                    if (!r.mapped) flag |= 4;
-                    if (rev) flag |= 16;
-                    if (mr.mapped && mr.primary.is_rev) flag |= 32;
-                    long long tlen = 0;
+                    a.flag |= 1u | (i < nPairs ? 64u : 128u);
+                    if (!mr.mapped) a.flag |= 8;
+                    if (mr.mapped && mr.primary.is_rev) a.flag |= 32;
                     if (r.mapped && mr.mapped && r.paired)
                     {
                         const bool oneBeforeTwo = r.primary.begin < mr.primary.begin;
-                        if ((!r.primary.is_rev && mr.primary.is_rev && oneBeforeTwo) || (!mr.primary.is_rev && r.primary.is_rev && !oneBeforeTwo)) flag |= 2;
+                        if ((!r.primary.is_rev && mr.primary.is_rev && oneBeforeTwo) || (!mr.primary.is_rev && r.primary.is_rev && !oneBeforeTwo)) a.flag |= 2;
                         if (r.primary.contig == mr.primary.contig)
-                            tlen = oneBeforeTwo ? (long long)mr.primary.begin + mr.primary.length - (long long)r.primary.begin
-                                                : (long long)mr.primary.begin - ((long long)r.primary.begin + r.primary.length);
+                            a.tlen = (int32_t)(oneBeforeTwo ? (long long)mr.primary.begin + mr.primary.length - (long long)r.primary.begin
+                                                            : (long long)mr.primary.begin - ((long long)r.primary.begin + r.primary.length));
                     }
-                    rec += '\t'; appendUint(rec, flag); rec += '\t';
-                    const dy_match * posOf = r.mapped ? &r.primary : (mr.mapped ? &mr.primary : nullptr);
-                    if (posOf) { rec += dy_index_contig_name(idx, posOf->contig); rec += '\t'; appendUint(rec, (unsigned long long)posOf->begin + 1); }
-                    else rec += "*\t0";
-                    rec += '\t'; appendUint(rec, r.mapped ? r.mapq : 0); rec += '\t';
-                    if (r.mapped) for (uint32_t k = 0; k < r.cigar_len; ++k) { uint32_t op = cg[r.cigar_begin + k]; appendUint(rec, op >> 4); rec += "MID"[op & 15]; }
-                    else rec += '*';
-                    rec += '\t';
-                    if (mr.mapped)
-                    {
-                        if (posOf && posOf->contig == mr.primary.contig) rec += '='; else rec += dy_index_contig_name(idx, mr.primary.contig);
-                        rec += '\t'; appendUint(rec, (unsigned long long)mr.primary.begin + 1);
-                    }
-                    else if (r.mapped) { rec += "=\t"; appendUint(rec, (unsigned long long)r.primary.begin + 1); }
-                    else rec += "*\t0";
-                    rec += '\t';
-                    if (tlen < 0) { rec += '-'; appendUint(rec, (unsigned long long)(-tlen)); } else appendUint(rec, (unsigned long long)tlen);
-                    rec += '\t';
+                    if (!r.mapped && mr.mapped) { a.rid = (int32_t)mr.primary.contig; a.pos = (int32_t)mr.primary.begin; }     // an unmapped mate sits at its mate's position
+                    if (mr.mapped) { a.rnext = (int32_t)mr.primary.contig; a.pnext = (int32_t)mr.primary.begin; }
+                    else if (r.mapped) { a.rnext = a.rid; a.pnext = a.pos; }
                 }
-                else if (!r.mapped) rec += "\t4\t*\t0\t0\t*\t*\t0\t0\t";
-                else
-                {
-                    rec += rev ? "\t16\t" : "\t0\t";
-                    rec += dy_index_contig_name(idx, r.primary.contig); rec += '\t';
-                    appendUint(rec, (unsigned long long)r.primary.begin + 1); rec += '\t';
-                    appendUint(rec, r.mapq); rec += '\t';
-                    for (uint32_t k = 0; k < r.cigar_len; ++k) { uint32_t op = cg[r.cigar_begin + k]; appendUint(rec, op >> 4); rec += "MID"[op & 15]; }
-                    rec += "\t*\t0\t0\t";
-                }
-                if (!rev) { for (size_t k = 0; k < len; ++k) rec += "ACGTN"[codes[k]]; rec += '\t'; rec.append(quals, len); }
-                else
-                {
-                    for (size_t k = 0; k < len; ++k) { u8 c = codes[len - 1 - k]; rec += "ACGTN"[c < 4 ? 3 - c : 4]; }
-                    rec += '\t';
-                    for (size_t k = 0; k < len; ++k) rec += quals[len - 1 - k];
-                }
-                if (r.mapped)
-                {
-                    rec += "\tNM:i:"; appendUint(rec, r.primary.errors);
-                    rec += "\tX0:i:"; appendUint(rec, r.best_count);
-                    rec += "\tX1:i:"; appendUint(rec, r.sub_count);
-                }
-                rec += "\tRG:Z:"; rec += opt.readGroup;
+                a.seq.resize(len); a.qual.resize(len);
+                if (!rev) for (size_t k = 0; k < len; ++k) { a.seq[k] = "ACGTN"[codes[k]]; a.qual[k] = quals[k]; }
+                else for (size_t k = 0; k < len; ++k) { u8 c = codes[len - 1 - k]; a.seq[k] = "ACGTN"[c < 4 ? 3 - c : 4]; a.qual[k] = quals[len - 1 - k]; }
+                if (r.mapped) { a.hasCounts = true; a.nm = r.primary.errors; a.x0 = r.best_count; a.x1 = r.sub_count; }
+                a.rg = opt.readGroup;
                 if (r.mapped)
                 {   // XA: every entry of matchesSet except the primary (first entry with the primary's contig/strand/begin)
-                    bool skipped = false, any = false;
+                    bool skipped = false;
                     const uint32_t nset = r.best_count + r.sub_count;
                     for (uint32_t k = 0; k < nset; ++k)
                     {
                         const dy_match & m = ms[r.set_begin + k];
                         if (!skipped && m.contig == r.primary.contig && m.is_rev == r.primary.is_rev && m.begin == r.primary.begin) { skipped = true; continue; }
-                        if (!any) { rec += "\tXA:Z:"; any = true; }
-                        rec += dy_index_contig_name(idx, m.contig); rec += ',';
-                        appendUint(rec, (unsigned long long)m.begin + 1); rec += ',';
-                        appendUint(rec, (unsigned long long)m.begin + m.length + 1); rec += ',';
-                        rec += m.is_rev ? '-' : '+'; rec += ',';
-                        appendUint(rec, m.errors); rec += ';';
+                        a.xa += contigNames[m.contig]; a.xa += ',';
+                        appendUint(a.xa, (unsigned long long)m.begin + 1); a.xa += ',';
+                        appendUint(a.xa, (unsigned long long)m.begin + m.length + 1); a.xa += ',';
+                        a.xa += m.is_rev ? '-' : '+'; a.xa += ',';
+                        appendUint(a.xa, m.errors); a.xa += ';';
                     }
                 }
-                rec += '\n';
-                os << rec;
+                if (bam) bamWriteRecord(bgzf, a, bamScratch);
+                else { rec.clear(); samWriteRecord(rec, a, contigNames); os << rec; }
                 mapped += r.mapped;
             }
             total += batch.size();
             dy_result_free(res);
             dy_reads_free(reads);
         }
+        if (bam) bgzf.finish();
         os.flush();
         if (opt.verbose)
         {

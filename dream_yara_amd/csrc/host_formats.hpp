@@ -13,6 +13,9 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#ifdef DY_HAVE_ZLIB
+#include <zlib.h>
+#endif
 
 namespace dy {
 
@@ -199,7 +202,32 @@ struct ReadsBatch
 class ReadsFile
 {
 public:
-    explicit ReadsFile(const std::string & path) : map_(path), p_(map_.data()), end_(map_.data() + map_.size()) {}
+    // plain or gzip-compressed FASTA/FASTQ (reference src/d_mapper.cpp:120-138 accepts .gz through SeqAn's stream layer);
+    // a compressed file is inflated into memory once
+    explicit ReadsFile(const std::string & path) : map_(path), p_(map_.data()), end_(map_.data() + map_.size())
+    {
+        if (map_.size() >= 2 && map_.data()[0] == 0x1f && map_.data()[1] == 0x8b)
+        {
+#ifdef DY_HAVE_ZLIB
+            gzFile f = gzopen(path.c_str(), "rb");
+            if (!f) throw IoError("Error while opening reads file.");
+            std::vector<u8> chunk(1 << 22);
+            for (;;)
+            {
+                int n = gzread(f, chunk.data(), (unsigned)chunk.size());
+                if (n < 0) { gzclose(f); throw IoError("corrupt gzip stream in " + path); }
+                if (n == 0) break;
+                inflated_.insert(inflated_.end(), chunk.begin(), chunk.begin() + n);
+            }
+            gzclose(f);
+            p_ = inflated_.data(); end_ = inflated_.data() + inflated_.size();
+#else
+            throw IoError("gzip-compressed input needs a build with zlib");
+#endif
+        }
+        else if (map_.size() >= 3 && map_.data()[0] == 'B' && map_.data()[1] == 'Z' && map_.data()[2] == 'h')
+            throw IoError("bzip2-compressed input is not supported (no libbz2 on this system)");
+    }
     // appends up to maxReads records; returns the number appended
     size_t next(ReadsBatch & b, size_t maxReads)
     {
@@ -246,6 +274,7 @@ private:
         return std::string((const char *)s, (const char *)e);
     }
     MappedFile map_;
+    std::vector<u8> inflated_;
     const u8 * p_; const u8 * end_;
 };
 
