@@ -92,6 +92,8 @@ SYMBOLS = [
     ("dy_result_cigars", _P, [_P]),
     ("dy_result_free", None, [_P]),
     ("dy_map_get_stats", C.c_int, [_P, C.POINTER(MapStats)]),
+    ("dy_kdx_create", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    ("dy_kdx_load", C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     ("dy_index_load_sharded", C.c_int, [_P, C.c_char_p, C.c_uint32, _P, C.POINTER(_P)]),
     ("dy_shard_plan", C.c_int, [_P, _P, C.c_uint32, _P, _P, _P]),
     ("dy_shard_pack", C.c_int, [_P, _P, _P, _P, _P, _P]),
@@ -167,6 +169,19 @@ class Ibf:
     def create(cls, ctx, n_bins, n_hashes, kmer_size, n_bits):
         h = _P()
         _check(ctx.lib.dy_ibf_create(ctx.h, n_bins, n_hashes, kmer_size, n_bits, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def load_direct(cls, ctx, path):
+        """-ft kmer_direct: the k-mer direct-addressing filter (reference src/d_kdx_filter.h)."""
+        h = _P()
+        _check(ctx.lib.dy_kdx_load(ctx.h, os.fsencode(path), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def create_direct(cls, ctx, n_bins, kmer_size):
+        h = _P()
+        _check(ctx.lib.dy_kdx_create(ctx.h, n_bins, kmer_size, C.byref(h)))
         return cls(ctx, h)
 
     def add(self, codes, bin_no):

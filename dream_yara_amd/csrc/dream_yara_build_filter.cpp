@@ -12,7 +12,7 @@ int main(int argc, char ** argv)
     try
     {
         unsigned bins = 64, k = 20, nh = 3; unsigned long long bs = 1, rawBits = 0;
-        std::string out, dir;
+        std::string out, dir, ftype = "bloom";
         for (int i = 1; i < argc; ++i)
         {
             std::string a = argv[i];
@@ -24,7 +24,7 @@ int main(int argc, char ** argv)
             else if (a == "--bits") rawBits = std::stoull(value());          // extension: exact size in bits (small test filters)
             else if (a == "-o" || a == "--output-file") out = value();
             else if (a == "-t" || a == "--threads") value();
-            else if (a == "-ft" || a == "--filter-type") { if (value() != "bloom") throw IoError("only -ft bloom is implemented"); }
+            else if (a == "-ft" || a == "--filter-type") { ftype = value(); if (ftype != "bloom" && ftype != "kmer_direct") throw IoError("filter type must be bloom or kmer_direct"); }
             else if (a == "-v" || a == "--verbose") {}
             else if (a.size() > 1 && a[0] == '-') throw IoError("unknown option " + a);
             else dir = a;
@@ -48,7 +48,12 @@ int main(int argc, char ** argv)
         dy_ctx * ctx = nullptr; dy_ibf * f = nullptr;
         auto check = [](int rc) { if (rc != DY_OK) throw IoError(dy_last_error()); };
         check(dy_ctx_create(0, &ctx));
-        check(dy_ibf_create(ctx, bins, nh, k, bits, &f));
+        if (ftype == "kmer_direct")
+        {   // reference src/d_build_filter.cpp:305-312: 4^k positions; the 32-bit shift there limits k to 15
+            if (k > 15) throw IoError("kmer_direct: kmer-size must be within [14,15]");
+            check(dy_kdx_create(ctx, bins, k, &f));
+        }
+        else check(dy_ibf_create(ctx, bins, nh, k, bits, &f));
         for (unsigned b = 0; b < bins; ++b)
             for (auto & r : readFasta(dir + std::to_string(b) + ext))
                 check(dy_ibf_add(f, r.codes.data(), r.codes.size(), b));

@@ -91,14 +91,13 @@ int main(int argc, char ** argv)
     try
     {
         CliOptions opt = parse(argc, argv);
-        if (opt.filterType == "kmer_direct") fail("filter type kmer_direct is not implemented (DY_EUNSUPPORTED)");
         auto t0 = std::chrono::steady_clock::now();
         dy_ctx * ctx = nullptr; check(dy_ctx_create(0, &ctx));
         dy_ibf * ibf = nullptr;
         uint32_t nBins = 0;
-        if (opt.filterType == "bloom")
-        {
-            check(dy_ibf_load(ctx, opt.filterFile.c_str(), &ibf));
+        if (opt.filterType == "bloom" || opt.filterType == "kmer_direct")
+        {   // reference src/d_mapper.h:910-936
+            check(opt.filterType == "bloom" ? dy_ibf_load(ctx, opt.filterFile.c_str(), &ibf) : dy_kdx_load(ctx, opt.filterFile.c_str(), &ibf));
             dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
             nBins = info.n_bins;                                                                                // readFilterMetadata :532-548
         }

@@ -22,6 +22,8 @@ struct IbfGeom
     u32 nHashes;
     u32 kmerSize;
     u32 W;               // 64-bit words per hash position
+    u32 direct;          // 1 = k-mer direct addressing (reference src/d_kdx_filter.h): position = the k-mer hash itself, one 'hash function'
+    u32 pad_;
     u64 preCalc[8];      // i ^ (k * 0x90b45d39fb6da1fa)
 };
 

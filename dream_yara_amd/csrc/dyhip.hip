@@ -475,6 +475,56 @@ int dy_ibf_load(dy_ctx * ctx, const char * path, dy_ibf ** out)
     });
 }
 
+// ---- k-mer direct-addressing filter (-ft kmer_direct): same handle, same query / add / save entry points
+static void makeDirect(dy_ctx * ctx, dy_ibf * f)
+{
+    f->g.direct = 1; f->g.nHashes = 1;
+    const u64 positions = f->g.kmerSize >= 32 ? ~0ull : (1ull << (2 * f->g.kmerSize));
+    if (f->g.nHashPos > positions) f->g.nHashPos = positions;
+    // zeroed guard position behind the table (it overlays the trailer, whose fields live in IbfGeom)
+    const size_t guard = (size_t)f->g.nHashPos * f->g.W;
+    HIP_CHECK(hipMemsetAsync(f->words.as<u64>() + guard, 0, (size_t)f->g.W * 8, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+
+int dy_kdx_create(dy_ctx * ctx, uint32_t n_bins, uint32_t kmer_size, dy_ibf ** out)
+{
+    return guarded([&] {
+        if (!ctx || !out) throw DyError(DY_EINVAL, "dy_kdx_create: NULL argument");
+        if (kmer_size == 0 || kmer_size > 16) throw DyError(DY_EUNSUPPORTED, "kmer_direct: k-mer size must be in [1,16]");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u64 W = ((u64)n_bins + 63) / 64;
+        const u64 bits = (1ull << (2 * kmer_size)) * 64 * W + 256;      // reference src/d_build_filter.cpp:307-309 (bins a multiple of 64)
+        std::unique_ptr<dy_ibf> f(new dy_ibf);
+        f->ctx = ctx;
+        initGeom(f->g, n_bins, 1, kmer_size, bits);
+        f->nWords = (size_t)(bits / 64);
+        f->words.reserve((f->nWords + W + 8) * 8);
+        HIP_CHECK(hipMemsetAsync(f->words.p, 0, (f->nWords + W + 8) * 8, ctx->stream));
+        makeDirect(ctx, f.get());
+        *out = f.release();
+    });
+}
+
+int dy_kdx_load(dy_ctx * ctx, const char * path, dy_ibf ** out)
+{
+    return guarded([&] {
+        if (!ctx || !path || !out) throw DyError(DY_EINVAL, "dy_kdx_load: NULL argument");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        FilterFile ff(path);
+        u64 ms = ff.nBits - 256;                                // reference src/d_kdx_filter.h:218-227
+        u32 bins = (u32)ff.getInt(ms), k = (u32)ff.getInt(ms + 128);
+        std::unique_ptr<dy_ibf> f(new dy_ibf);
+        f->ctx = ctx;
+        initGeom(f->g, bins, 1, k, ff.nBits);
+        f->nWords = ff.nWords;
+        f->words.reserve((f->nWords + f->g.W + 8) * 8);
+        HIP_CHECK(hipMemcpy(f->words.p, ff.words, f->nWords * 8, hipMemcpyHostToDevice));
+        makeDirect(ctx, f.get());
+        *out = f.release();
+    });
+}
+
 int dy_ibf_add(dy_ibf * f, const uint8_t * seq, uint64_t len, uint32_t bin)
 {
     return guarded([&] {
@@ -501,7 +551,7 @@ int dy_ibf_save(dy_ibf * f, const char * path)
         std::vector<u64> host(f->nWords);
         HIP_CHECK(hipMemcpy(host.data(), f->words.p, f->nWords * 8, hipMemcpyDeviceToHost));
         size_t ms = (size_t)((f->g.nBits - 256) / 64);          // _setMetadata, reference src/d_bloom_filter.h:267-277
-        host[ms] = f->g.nBins; host[ms + 1] = f->g.nHashes; host[ms + 2] = f->g.kmerSize;
+        host[ms] = f->g.nBins; host[ms + 1] = f->g.direct ? 0 : f->g.nHashes; host[ms + 2] = f->g.kmerSize; host[ms + 3] = 0;
         FILE * fp = fopen(path, "wb");
         if (!fp) throw IoError(std::string("cannot write ") + path);
         bool ok = fwrite(&f->g.nBits, 8, 1, fp) == 1 && fwrite(host.data(), 8, host.size(), fp) == host.size();

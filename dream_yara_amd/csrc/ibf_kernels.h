@@ -41,6 +41,9 @@ __device__ __forceinline__ u64 waveOr64(u64 v)
 // Hash position (in 64-bit words) of k-mer hash `h` under hash function i (reference src/d_bloom_filter.h:286-291).
 __device__ __forceinline__ u64 ibfWordIndex(const IbfGeom & g, u64 kmerHash, u32 i)
 {
+    // kmer_direct (reference src/d_kdx_filter.h:155-159): the hash is the position; hashes beyond the table (k-mers poisoned
+    // by a leading N) land on the all-zero guard position nHashPos that dy_kdx_* allocate behind the table
+    if (g.direct) return (kmerHash < g.nHashPos ? kmerHash : g.nHashPos) * g.W;
     u64 v = g.preCalc[i] * kmerHash;
     v ^= v >> 27;
     if (g.hashPosMask) v &= g.hashPosMask;
@@ -442,6 +445,7 @@ __global__ void k_ibf_insert(u64 * __restrict__ words, IbfGeom g, const u8 * __r
     for (u32 t = 0; t < k; ++t) { u32 c = seq[i + t]; hash = hash * 4 + (c > 3 ? 0 : c); }
     if (seq[0] > 3 && 2 * (k + i) < 64) hash += 1ull << (2 * (k + i));
     const u64 bitInWord = bin & 63, wordInPos = bin >> 6;
+    if (g.direct && hash >= g.nHashPos) return;
     for (u32 hf = 0; hf < g.nHashes; ++hf)
         atomicOr((unsigned long long *)&words[ibfWordIndex(g, hash, hf) + wordInPos], 1ull << bitInWord);
 }

@@ -74,6 +74,14 @@ void dy_ibf_free(dy_ibf *f);
 /* DisOptions::getThreshold — reference src/d_mapper.h:83-92.  error_rate is the float the CLI stores (e/100.0). */
 uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len);
 
+/* k-mer direct-addressing filter, `-ft kmer_direct` — SeqAnKDXFilter, reference src/d_kdx_filter.h:45-268 (built by
+ * src/d_build_filter.cpp:305-312, used by src/d_mapper.h:924-936).  One table position per possible k-mer (4^k positions of
+ * W words), the k-mer's own hash is the position, no hash functions.  The handle is a dy_ibf: dy_ibf_add / dy_ibf_query /
+ * dy_ibf_save / dy_ibf_get_info (n_hashes = 1) / dy_ibf_free apply.  The reference only bounds the hash by 64x the table
+ * size and reads past the vector for k-mers poisoned by a leading N; here such k-mers select no bin. */
+int  dy_kdx_create(dy_ctx *ctx, uint32_t n_bins, uint32_t kmer_size, dy_ibf **out);
+int  dy_kdx_load(dy_ctx *ctx, const char *path, dy_ibf **out);
+
 /* ---- reads ------------------------------------------------------------------------------------------- */
 /* Uploads a batch: `seqs` = concatenated Dna5 codes of the FORWARD reads, `offs` = n_reads+1 offsets.
  * The reverse complements (reference src/store_seqs.h:271-290, appendReverseComplement) are derived on the device.

@@ -270,6 +270,7 @@ struct IBF
     u32 binIntWidth = 0;      // W
     u32 blockBitSize = 0;     // 64 W
     u64 noOfHashPos = 0;
+    bool direct = false;      // k-mer direct-addressing filter (reference src/d_kdx_filter.h): position = the k-mer's own hash
     std::vector<u64> preCalc;
     std::vector<u64> words;   // ceil(bits/64)
 
@@ -282,6 +283,10 @@ struct IBF
         binIntWidth = (noOfBins + 63) / 64;
         blockBitSize = binIntWidth * 64;
         noOfHashPos = (noOfBits - 256) / blockBitSize;
+        // kmer_direct: the reference bounds the hash by (bits-256)/W (src/d_kdx_filter.h:215), 64x the number of blocks the
+        // vector holds, i.e. it reads past the vector for larger hashes; here such k-mers (only those poisoned by a leading N,
+        // SURVEY B.3) select no bin.
+        if (direct) noOfHashFunc = 1;
         preCalc.resize(noOfHashFunc);
         for (u32 i = 0; i < noOfHashFunc; ++i) preCalc[i] = (u64)i ^ ((u64)kmerSize * SEED);
     }
@@ -291,6 +296,12 @@ struct IBF
         u64 w = idx >> 6; unsigned o = idx & 63;
         if (!o) return words[w];
         return (words[w] >> o) | (words[w + 1] << (64 - o));
+    }
+    // reference src/d_build_filter.cpp:305-312: 4^k positions of `bins` bits (+ trailer); defined for bins % 64 == 0
+    void createDirect(u32 bins, u32 k)
+    {
+        direct = true;
+        create(bins, 1, k, ((u64)1 << (2 * k)) * (((u64)bins + 63) / 64 * 64) + 256);
     }
     void create(u32 bins, u32 hashes, u32 k, u64 bits)
     {
@@ -303,7 +314,7 @@ struct IBF
     {
         u64 ms = noOfBits - 256;   // bits; 256-aligned iff noOfBits is (bs*2^33+256 is)
         if (ms % 64) throw std::runtime_error("unaligned IBF trailer not supported");
-        words[ms / 64] = noOfBins; words[ms / 64 + 1] = noOfHashFunc; words[ms / 64 + 2] = kmerSize;
+        words[ms / 64] = noOfBins; words[ms / 64 + 1] = direct ? 0 : noOfHashFunc; words[ms / 64 + 2] = kmerSize;     // kdx: src/d_kdx_filter.h:231-238
     }
     void save(const std::string & path)
     {
@@ -314,8 +325,9 @@ struct IBF
         fwrite(words.data(), 8, words.size(), f);
         fclose(f);
     }
-    void load(const std::string & path)
+    void load(const std::string & path, bool asDirect = false)
     {
+        direct = asDirect;
         FILE * f = fopen(path.c_str(), "rb");
         if (!f) throw std::runtime_error("File \"" + path + "\" could not be read.");
         if (fread(&noOfBits, 8, 1, f) != 1) { fclose(f); throw std::runtime_error("bad filter"); }

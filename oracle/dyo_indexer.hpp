@@ -271,6 +271,7 @@ inline void forEachKmerHash(const u8 * text, size_t len, unsigned k, F && f)
 // reference src/d_bloom_filter.h:286-291
 inline u64 ibfHashPos(const IBF & f, u64 kmerHash, unsigned i)
 {
+    if (f.direct) return kmerHash * f.blockBitSize;          // reference src/d_kdx_filter.h:159,258
     u64 v = f.preCalc[i] * kmerHash;
     v ^= v >> IBF::SHIFT;
     v %= f.noOfHashPos;
@@ -282,6 +283,7 @@ inline u64 ibfHashPos(const IBF & f, u64 kmerHash, unsigned i)
 inline void ibfAddKmers(IBF & f, const u8 * text, size_t len, u32 binNo)
 {
     forEachKmerHash(text, len, f.kmerSize, [&](size_t, u64 h) {
+        if (f.direct && h >= f.noOfHashPos) return;
         for (unsigned i = 0; i < f.noOfHashFunc; ++i)
         {
             u64 bit = ibfHashPos(f, h, i) + binNo;

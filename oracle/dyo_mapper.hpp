@@ -76,6 +76,7 @@ inline void ibfWhichBins(const IBF & f, std::vector<bool> & selected, const u8 *
 {
     std::vector<u16> counts(f.noOfBins, 0);
     forEachKmerHash(text, len, f.kmerSize, [&](size_t, u64 h) {
+        if (f.direct && h >= f.noOfHashPos) return;              // src/d_kdx_filter.h:155-156
         u64 idx[8];
         for (unsigned i = 0; i < f.noOfHashFunc; ++i) idx[i] = ibfHashPos(f, h, i);
         for (u32 batch = 0; batch < f.binIntWidth; ++batch)

@@ -9,7 +9,7 @@ int main(int argc, char ** argv)
 {
     try
     {
-        u32 bins = 64, k = 20, nh = 3; u64 bits = 0; std::string out, split;
+        u32 bins = 64, k = 20, nh = 3; u64 bits = 0; std::string out, split, ftype = "bloom";
         for (int i = 1; i < argc; ++i)
         {
             std::string a = argv[i];
@@ -20,11 +20,14 @@ int main(int argc, char ** argv)
             else if (a == "-bs") bits = std::stoull(next()) * 8589934592ull + 256;
             else if (a == "--bits") bits = std::stoull(next()) + 256;
             else if (a == "-o") out = next();
+            else if (a == "-ft") ftype = next();
             else if (a == "--split") split = next();
             else throw std::runtime_error("unknown option " + a);
         }
-        if (!bits || out.empty() || split.empty()) throw std::runtime_error("need -bs/--bits, -o, --split");
-        IBF f; f.create(bins, nh, k, bits);
+        const bool direct = ftype == "kmer_direct";
+        if ((!bits && !direct) || out.empty() || split.empty()) throw std::runtime_error("need -bs/--bits, -o, --split");
+        IBF f;
+        if (direct) f.createDirect(bins, k); else f.create(bins, nh, k, bits);
         SeqReader rd(split); SeqRecords r; rd.read(r, ~(size_t)0);
         for (size_t i = 0; i < r.seqs.size() && i < bins; ++i)
         {

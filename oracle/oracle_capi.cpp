@@ -33,6 +33,25 @@ void * dyo_ibf_load(const char * path)
 {
     try { IBF * f = new IBF; f->load(path); return f; } catch (std::exception const & e) { g_err = e.what(); return nullptr; }
 }
+void * dyo_kdx_load(const char * path)
+{
+    try { IBF * f = new IBF; f->load(path, true); return f; } catch (std::exception const & e) { g_err = e.what(); return nullptr; }
+}
+int dyo_kdx_build(const char * path, u32 bins, u32 k, const u8 * seqs, const u64 * offs, u32 nSeqs)
+{
+    try
+    {
+        IBF f; f.createDirect(bins, k);
+        for (u32 i = 0; i < nSeqs && i < bins; ++i)
+        {
+            size_t len = (size_t)(offs[i + 1] - offs[i]);
+            if (len >= k) ibfAddKmers(f, seqs + offs[i], len, i);
+        }
+        f.save(path);
+        return 0;
+    }
+    catch (std::exception const & e) { g_err = e.what(); return -1; }
+}
 void dyo_ibf_free(void * f) { delete (IBF *)f; }
 void dyo_ibf_info(void * f, u64 * out) { IBF * i = (IBF *)f; out[0] = i->noOfBits; out[1] = i->noOfBins; out[2] = i->noOfHashFunc; out[3] = i->kmerSize; out[4] = i->binIntWidth; out[5] = i->noOfHashPos; }
 

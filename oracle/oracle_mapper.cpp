@@ -50,6 +50,7 @@ int main(int argc, char ** argv)
         IBF filter;
         u32 numberOfBins = 0;
         if (filterType == "bloom") { filter.load(filterFile); numberOfBins = filter.noOfBins; }
+        else if (filterType == "kmer_direct") { filter.load(filterFile, true); numberOfBins = filter.noOfBins; }
         else if (filterType == "none")
         {
             opt.useFilter = false;

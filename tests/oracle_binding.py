@@ -22,6 +22,8 @@ def lib():
         P = C.c_void_p
         l.dyo_last_error.restype = C.c_char_p
         l.dyo_ibf_load.restype = P; l.dyo_ibf_load.argtypes = [C.c_char_p]
+        l.dyo_kdx_load.restype = P; l.dyo_kdx_load.argtypes = [C.c_char_p]
+        l.dyo_kdx_build.restype = C.c_int; l.dyo_kdx_build.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, P, P, C.c_uint32]
         l.dyo_ibf_free.argtypes = [P]
         l.dyo_ibf_info.argtypes = [P, P]
         l.dyo_ibf_query.restype = C.c_int; l.dyo_ibf_query.argtypes = [P, P, P, C.c_uint32, C.c_uint16, P]
@@ -48,8 +50,9 @@ def _err():
 
 
 class OracleIbf:
-    def __init__(self, path):
-        self.h = lib().dyo_ibf_load(os.fsencode(path))
+    def __init__(self, path, direct=False):
+        """direct=True: the k-mer direct-addressing filter of -ft kmer_direct (reference src/d_kdx_filter.h)."""
+        self.h = (lib().dyo_kdx_load if direct else lib().dyo_ibf_load)(os.fsencode(path))
         if not self.h:
             raise _err()
         info = np.zeros(6, dtype=np.uint64)
@@ -75,6 +78,13 @@ def build_filter(path, bins, hashes, k, bits, codes, offs):
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     if lib().dyo_ibf_build(os.fsencode(path), bins, hashes, k, bits, codes.ctypes.data, offs.ctypes.data, offs.size - 1):
+        raise _err()
+
+
+def build_direct_filter(path, bins, k, codes, offs):
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    if lib().dyo_kdx_build(os.fsencode(path), bins, k, codes.ctypes.data, offs.ctypes.data, offs.size - 1):
         raise _err()
 
 

@@ -521,6 +521,94 @@ def test_cli_paired_end_sam_equals_oracle_cli(product_build, oracle_build, ob, t
     assert sum(1 for f in flags if f & 2) > n_pairs          # most pairs are proper
 
 
+@pytest.mark.parametrize("bins,k", [(64, 8), (64, 11), (192, 9), (64, 4)])
+def test_kmer_direct_filter_matches_oracle(dy, ctx, ob, tmp_path, bins, k):
+    """-ft kmer_direct (reference src/d_kdx_filter.h): file written by the device == file written by the oracle, and the
+    bin masks agree, incl. reads with a leading N (whose poisoned hashes fall outside the table)."""
+    rng = np.random.default_rng(bins * 100 + k)
+    genomes = [rng.integers(0, 4, 3000, dtype=np.uint8) for _ in range(bins)]
+    genomes[3][100] = 4; genomes[5][0] = 4
+    goffs = np.zeros(bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    fo, fd = str(tmp_path / "o.kdx"), str(tmp_path / "d.kdx")
+    ob.build_direct_filter(fo, bins, k, np.concatenate(genomes), goffs)
+    f = dy.Ibf.create_direct(ctx, bins, k)
+    for b, g in enumerate(genomes):
+        f.add(g, b)
+    f.save(fd); f.close()
+    assert open(fo, "rb").read() == open(fd, "rb").read()
+    reads = []
+    for i in range(400):
+        b = int(rng.integers(0, bins)); L = int(rng.integers(max(k, 20), 120)); s = int(rng.integers(0, 3000 - L))
+        r = genomes[b][s:s + L].copy()
+        for _ in range(int(rng.integers(0, 3))): r[int(rng.integers(0, L))] = rng.integers(0, 4)
+        if i % 7 == 0: r[0] = 4
+        if i % 11 == 0: r[-1] = 4
+        if i % 2: r = np.where(r[::-1] < 4, 3 - r[::-1], 4).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    reads.append(np.zeros(k - 1, np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    f = dy.Ibf.load_direct(ctx, fo)
+    assert f.info()["n_hashes"] == 1 and f.info()["kmer_size"] == k and f.info()["n_bins"] == bins
+    oibf = ob.OracleIbf(fo, direct=True)
+    r = dy.Reads(ctx, codes, offs)
+    for thr in (0, 1, 5, 30):
+        assert np.array_equal(f.query(r, thr), oibf.query(codes, offs, thr)), thr
+    r.close(); f.close(); oibf.close()
+
+
+def test_map_with_kmer_direct_filter_matches_oracle(dy, ctx, ob, tmp_path):
+    rng = np.random.default_rng(515)
+    n_bins, k = 6, 10
+    genomes, fam = _repeat_genomes(rng, n_bins, 30000)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    fpath = str(tmp_path / "f.kdx")
+    ob.build_direct_filter(fpath, n_bins, k, np.concatenate(genomes), goffs)
+    codes, offs = _sample_reads(rng, genomes, fam, 1500, 100, 3)
+    er = np.float32(0.03)
+    idx = dy.Index(ctx, idx_dir, n_bins); reads = dy.Reads(ctx, codes, offs); f = dy.Ibf.load_direct(ctx, fpath)
+    f.query(reads, dy.threshold(er, k, 100), want_masks=False)
+    res = dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=er))
+    dev = (res.reads(), res.matches(), res.cigars()); stats = ctx.stats()
+    res.close(); reads.close(); idx.close(); f.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath, direct=True)
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er, np.float32(0))
+    assert stats["items"] == ostats["items"] and stats["items"] < 1502 * n_bins          # the filter does filter
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
+    oidx.close(); oibf.close()
+
+
+def test_cli_kmer_direct_equals_oracle_cli(product_build, oracle_build, tmp_path):
+    """dream_yara_build_filter -ft kmer_direct -k 14 (2 GiB table) + dream_yara_mapper -ft kmer_direct on the reference's
+    test data; the filter file and the SAM equal the oracle tools' output."""
+    fa_dir = tmp_path / "bins"; fa_dir.mkdir()
+    recs = open(os.path.join(GOLDEN, "input", "64-viral-genomes.fa")).read().split(">")[1:]
+    assert len(recs) == 64
+    for b, rec in enumerate(recs):
+        (fa_dir / ("%d.fna" % b)).write_text(">" + rec)
+    mine, ref = str(tmp_path / "mine.kdx"), str(tmp_path / "ref.kdx")
+    subprocess.check_call([os.path.join(product_build, "dream_yara_build_filter"), "-b", "64", "-k", "14", "-ft", "kmer_direct", "-o", mine, str(fa_dir)])
+    subprocess.check_call([os.path.join(oracle_build, "oracle_build_filter"), "-b", "64", "-k", "14", "-ft", "kmer_direct", "-o", ref,
+                           "--split", os.path.join(GOLDEN, "input", "64-viral-genomes.fa")])
+    import hashlib
+    def md5(p):
+        h = hashlib.md5()
+        with open(p, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        return h.hexdigest()
+    assert os.path.getsize(mine) == 8 + (4 ** 14) * 8 + 32 and md5(mine) == md5(ref)
+    os.remove(ref)
+    a, b = str(tmp_path / "a.sam"), str(tmp_path / "b.sam")
+    subprocess.check_call([os.path.join(product_build, "dream_yara_mapper"), "-ft", "kmer_direct", "-fi", mine, GOLD_INDEX + "/", READS_FA, "-o", a, "-e", "3"])
+    subprocess.check_call([os.path.join(oracle_build, "oracle_mapper"), "-ft", "kmer_direct", "-fi", mine, GOLD_INDEX + "/", READS_FA, "-o", b, "-e", "3"])
+    os.remove(mine)
+    assert sam_records(a) == sam_records(b)
+    assert sam_records(a) == sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.t1.sam"))     # a filter without false negatives changes nothing
+
+
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
 @pytest.mark.parametrize("strata", [0.0, 0.02])
 def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata):
