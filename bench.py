@@ -188,7 +188,7 @@ def main():
         # HBM traffic of K1 per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
         # narrow gathers are accounted at 64 B per request, calibrated on scripts/ubench_gather.hip: profiles/r01_fetch_size_calibration.json)
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01e_pmc_config2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01g_pmc_config2.json")
         if args.workload == "config2" and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file)).get("void dy::k_ibf_query<7>", {})
             if "FETCH_SIZE" in pmc:
@@ -205,7 +205,7 @@ def main():
                        "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
             "roofline": {"kernel": "k_ibf_query", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "note": "algorithmic bytes %d B/read x %d reads per launch; every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result" % (bytes_per_read, wl["reads"])},
+                         "note": "algorithmic bytes %d B/read x %d reads per launch; every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87% busy at the same time (profiles/r01f_pmc_sq_config2.json)" % (bytes_per_read, wl["reads"])},
         }
         if args.cpu_sample > 0 and world == 1:
             fpath = os.path.join(work_dir, "bench.filter")
