@@ -205,7 +205,7 @@ def main():
                        "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
             "roofline": {"kernel": "k_ibf_query", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "note": "algorithmic bytes %d B/read x %d reads per launch; every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87% busy at the same time (profiles/r01f_pmc_sq_config2.json)" % (bytes_per_read, wl["reads"])},
+                         "note": "algorithmic bytes %d B/read x %d reads per launch; every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87%% busy at the same time (profiles/r01f_pmc_sq_config2.json)" % (bytes_per_read, wl["reads"])},
         }
         if args.cpu_sample > 0 and world == 1:
             fpath = os.path.join(work_dir, "bench.filter")

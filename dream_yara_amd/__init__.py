@@ -92,6 +92,7 @@ SYMBOLS = [
     ("dy_result_cigars", _P, [_P]),
     ("dy_result_free", None, [_P]),
     ("dy_map_get_stats", C.c_int, [_P, C.POINTER(MapStats)]),
+    ("dy_ibf_clear_bins", C.c_int, [_P, _P, C.c_uint32]),
     ("dy_kdx_create", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("dy_kdx_load", C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     ("dy_index_load_sharded", C.c_int, [_P, C.c_char_p, C.c_uint32, _P, C.POINTER(_P)]),
@@ -187,6 +188,10 @@ class Ibf:
     def add(self, codes, bin_no):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         _check(self.lib.dy_ibf_add(self.h, codes.ctypes.data, codes.size, bin_no))
+
+    def clear_bins(self, bins):
+        bins = np.ascontiguousarray(bins, dtype=np.uint32)
+        _check(self.lib.dy_ibf_clear_bins(self.h, bins.ctypes.data, bins.size))
 
     def save(self, path):
         _check(self.lib.dy_ibf_save(self.h, os.fsencode(path)))

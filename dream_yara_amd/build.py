@@ -45,7 +45,7 @@ def build(force=False):
         extra = os.environ.get("DY_HIPCC_FLAGS", "").split()       # tuning experiments only (e.g. -DDY_K3_WAVES=6)
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"] + extra + ["-o", LIB,
               os.path.join(CSRC, "dyhip.hip")])
-    for tool in ("dream_yara_mapper", "dream_yara_build_filter", "dream_yara_indexer"):
+    for tool in ("dream_yara_mapper", "dream_yara_build_filter", "dream_yara_update_filter", "dream_yara_indexer"):
         src = os.path.join(CSRC, tool + ".cpp")
         exe = os.path.join(CSRC, tool)
         if not os.path.exists(src):

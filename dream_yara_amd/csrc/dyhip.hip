@@ -81,7 +81,7 @@ struct dy_ctx
     DevBuf peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList;
+           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList;
     size_t poolCap = 0;
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
@@ -279,7 +279,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
         ctx->dp.reserve(dpStride * finWaves + 64);
         FinalizeArgs fa;
-        fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.nReads = nReads;
+        fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.readSeqsRc = rv.seqsRc; fa.nReads = nReads;
         fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
         fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
         fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
@@ -295,7 +295,10 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             u32 * smallCount = ctx->counters.as<u32>() + 5;
             hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
                                ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
-            hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount);
+            ctx->dpList.reserve((size_t)nReads * 4 + 64);
+            u32 * dpCount = ctx->counters.as<u32>() + 6;
+            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount);
+            hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->dpList.as<u32>(), dpCount);
             hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
             hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
         }
@@ -538,6 +541,27 @@ int dy_ibf_add(dy_ibf * f, const uint8_t * seq, uint64_t len, uint32_t bin)
         u64 nk = len - f->g.kmerSize + 1;
         u32 blocks = (u32)((nk + 255) / 256);
         hipLaunchKernelGGL(k_ibf_insert, dim3(blocks), dim3(256), 0, ctx->stream, f->words.as<u64>(), f->g, d.as<u8>(), len, bin);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int dy_ibf_clear_bins(dy_ibf * f, const uint32_t * bins, uint32_t n_bins)
+{
+    return guarded([&] {
+        if (!f || (!bins && n_bins)) throw DyError(DY_EINVAL, "dy_ibf_clear_bins: NULL argument");
+        std::vector<u64> mask(f->g.W, 0);
+        for (u32 i = 0; i < n_bins; ++i)
+        {
+            if (bins[i] >= f->g.nBins) throw DyError(DY_EINVAL, "dy_ibf_clear_bins: bin out of range");
+            mask[bins[i] / 64] |= 1ull << (bins[i] % 64);
+        }
+        if (!n_bins) return;
+        dy_ctx * ctx = f->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        DevBuf d; upload(d, mask);
+        const u64 nTable = f->g.nHashPos * f->g.W;
+        hipLaunchKernelGGL(k_ibf_clear_bins, dim3(256 * 32), dim3(256), 0, ctx->stream, f->words.as<u64>(), nTable, f->g.W, d.as<u64>());
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });

@@ -38,6 +38,7 @@ struct FinalizeArgs
     const u32 * readStart;        // nReads + 1
     const u64 * readOffs;         // read offsets (for lengths)
     const u8 *  readSeqs;
+    const u8 *  readSeqsRc;       // reverse complements, same offsets
     u32 nReads;
     const BinDesc * bins;
     const u8 * contigs; const u64 * limits;
@@ -259,6 +260,25 @@ __device__ inline u32 alignMatchDevice(const u8 * __restrict__ ctg, int n, const
         ++nc;
     }
     return nc;
+}
+
+// Is the banded DP's answer for a 2-error match of full read length certainly "<readLen>M, no shrink"?
+// With free contig end gaps (TTop/TBottom), mismatch -1000, gap open -1001 / extend -999, diagonal preferred on ties and the
+// LEFTMOST best cell of the last row, the main diagonal (score -2000) loses only to an alignment with exactly one inserted
+// base and no mismatch (-1001; it skips the first or the last contig base), or — on the leftmost-tie rule — to one 2-base
+// insertion without mismatches that leaves at least one trailing contig base unaligned (-2000, ends left of column n).
+// Those exist only if a prefix of the read matches the window and the rest matches it shifted by one or two bases, which
+// five LCPs rule out (conservatively).  `seq` is the read in the match's orientation.
+__device__ inline bool alignIsUngapped2(const u8 * __restrict__ ctg, const u8 * __restrict__ seq, int m)
+{
+    if (countMismatches(ctg, seq, m) != 2) return false;
+    const int lcpF = lcpForward(ctg, seq, m), lcpB = lcpBackward(ctg + m, seq + m, m);
+    const int LB1 = lcpBackward(ctg + m - 1, seq + m, m - 1), LB2 = lcpBackward(ctg + m - 2, seq + m, m - 2);     // read[x+g] == contig[x]
+    const int LF1 = lcpForward(ctg + 1, seq, m - 1), LF2 = lcpForward(ctg + 2, seq, m - 2);                        // read[x] == contig[x+g]
+    if (lcpF + LB1 >= m - 1 || lcpF + LB2 >= m - 2) return false;
+    if (LF1 + lcpB >= m - 1 || LF2 + lcpB >= m - 2) return false;
+    if (LF1 + LB1 >= m - 2) return false;
+    return true;
 }
 
 // Single-thread form for short reads and narrow bands (readLen <= 160, e <= 7): the three band rows live in registers
@@ -712,37 +732,87 @@ __device__ __forceinline__ void writeSingleMatch(const FinalizeArgs & A, u32 rea
     A.out[read] = ro;
 }
 
+// list[count++] = value for the lanes that want it: one atomic per wavefront and list
+__device__ __forceinline__ void waveAppend(bool want, u32 value, u32 * __restrict__ list, u32 * __restrict__ count)
+{
+    const u64 mask = __ballot(want);
+    if (!mask) return;
+    const u32 lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    u32 base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (u32)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) list[base + (u32)__popcll(mask & ((1ull << lane) - 1))] = value;
+}
+
 __global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount,
                                   u32 * __restrict__ alignList, u32 * __restrict__ alignCount, u32 * __restrict__ smallList, u32 * __restrict__ smallCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
-    if (read >= A.nReads) return;
-    const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
-    const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
-    ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
-    if (n == 0) { A.out[read] = ro; return; }
-    if (n == 1)
+    u32 route = 0;      // 0 = done here, 1 = align list, 2 = small list, 3 = complex list
+    if (read < A.nReads)
     {
-        const RawMatch a = A.gp[s0];
-        const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
-        if (!gapped)
+        const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+        const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
+        if (n == 0) A.out[read] = ro;
+        else
         {
-            A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1;
-            writeSingleMatch(A, read, ro, a);
-            return;
-        }
-        if (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
-        {   // alignment needed, but nothing to sort: queue for k_align_single (all lanes busy there)
-            alignList[atomicAdd(alignCount, 1u)] = read;
-            return;
+            route = 3;
+            if (n == 1)
+            {
+                const RawMatch a = A.gp[s0];
+                const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
+                if (!gapped)
+                {
+                    A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1;
+                    writeSingleMatch(A, read, ro, a);
+                    route = 0;
+                }
+                else if (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
+                    route = 1;      // alignment needed, but nothing to sort: k_align_check / k_align_single (all lanes busy there)
+            }
+            else if (n <= 4 && readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
+                route = 2;
         }
     }
-    if (n >= 2 && n <= 4 && readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
+    waveAppend(route == 1, read, alignList, alignCount);
+    waveAppend(route == 2, read, smallList, smallCount);
+    waveAppend(route == 3, read, complexList, complexCount);
+}
+
+// First pass over the align list: a 2-substitution match needs no DP when alignIsUngapped2 holds; the rest goes to dpList.
+__global__ __launch_bounds__(256) void k_align_check(FinalizeArgs A, const u32 * __restrict__ alignList, const u32 * __restrict__ alignCount,
+                                                     u32 * __restrict__ dpList, u32 * __restrict__ dpCount)
+{
+    const u32 nList = *alignCount;
+    for (u32 base = blockIdx.x * blockDim.x; base < nList; base += gridDim.x * blockDim.x)
     {
-        smallList[atomicAdd(smallCount, 1u)] = read;
-        return;
+        const u32 li = base + threadIdx.x;
+        bool needDp = false; u32 read = 0;
+        if (li < nList)
+        {
+            read = alignList[li];
+            const u32 s0 = A.readStart[read];
+            const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+            const RawMatch a = A.gp[s0];
+            needDp = true;
+            if (a.errors == 2 && a.len == readLen && readLen >= 8)
+            {
+                const BinDesc & bd = A.bins[a.bin];
+                const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+                const u8 * seq = (a.strand ? A.readSeqsRc : A.readSeqs) + A.readOffs[read];
+                if (alignIsUngapped2(ctg, seq, (int)readLen))
+                {
+                    ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
+                    A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1;
+                    writeSingleMatch(A, read, ro, a);
+                    needDp = false;
+                }
+            }
+        }
+        waveAppend(needDp, read, dpList, dpCount);
     }
-    complexList[atomicAdd(complexCount, 1u)] = read;
 }
 
 // alignMatches for reads whose only match needs the DP: CIGAR + shrink (reference src/mapper_aligner.h:204-236)

@@ -450,4 +450,15 @@ __global__ void k_ibf_insert(u64 * __restrict__ words, IbfGeom g, const u8 * __r
         atomicOr((unsigned long long *)&words[ibfWordIndex(g, hash, hf) + wordInPos], 1ull << bitInWord);
 }
 
+// clearBins (reference src/d_bloom_filter.h:99-123, src/d_kdx_filter.h:74-99): one streaming read-modify-write pass over the table
+__global__ void k_ibf_clear_bins(u64 * __restrict__ words, u64 nTableWords, u32 W, const u64 * __restrict__ clearMask)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nTableWords; i += stride)
+    {
+        const u64 m = clearMask[i % W];
+        if (m) words[i] &= ~m;
+    }
+}
+
 } // namespace dy

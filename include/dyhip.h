@@ -79,6 +79,9 @@ uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_le
  * W words), the k-mer's own hash is the position, no hash functions.  The handle is a dy_ibf: dy_ibf_add / dy_ibf_query /
  * dy_ibf_save / dy_ibf_get_info (n_hashes = 1) / dy_ibf_free apply.  The reference only bounds the hash by 64x the table
  * size and reads past the vector for k-mers poisoned by a leading N; here such k-mers select no bin. */
+/* clearBins — reference src/d_bloom_filter.h:99-123 (and src/d_kdx_filter.h:74-99), the first half of dream_yara_update_filter
+ * (src/d_update_filter.cpp:187-204): clears the given bins' bit in every hash position; dy_ibf_add then re-fills them. */
+int  dy_ibf_clear_bins(dy_ibf *f, const uint32_t *bins, uint32_t n_bins);
 int  dy_kdx_create(dy_ctx *ctx, uint32_t n_bins, uint32_t kmer_size, dy_ibf **out);
 int  dy_kdx_load(dy_ctx *ctx, const char *path, dy_ibf **out);
 

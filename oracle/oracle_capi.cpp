@@ -98,6 +98,15 @@ int dyo_ibf_build(const char * path, u32 bins, u32 hashes, u32 k, u64 bitsWithou
     catch (std::exception const & e) { g_err = e.what(); return -1; }
 }
 
+// alignMatch on raw codes (tests of the device's DP shortcuts): returns the number of CIGAR ops written as (len << 4) | op
+int dyo_align_match(const u8 * contig, int n, const u8 * read, int m, int errors, u32 * cigarOut, int cap, int * clipBegin, int * clipEnd)
+{
+    std::vector<CigarOp> c = alignMatch(contig, n, read, m, errors, *clipBegin, *clipEnd);
+    int k = 0;
+    for (auto & op : c) { if (k < cap) cigarOut[k] = (op.count << 4) | (op.op == 'M' ? 0u : op.op == 'I' ? 1u : 2u); ++k; }
+    return k;
+}
+
 void * dyo_index_load(const char * dir, u32 nBins)
 {
     try { std::string d(dir); while (d.size() > 1 && d.back() == '/') d.pop_back(); return new DreamIndex(loadDreamIndex(d, nBins)); }

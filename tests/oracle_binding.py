@@ -24,6 +24,8 @@ def lib():
         l.dyo_ibf_load.restype = P; l.dyo_ibf_load.argtypes = [C.c_char_p]
         l.dyo_kdx_load.restype = P; l.dyo_kdx_load.argtypes = [C.c_char_p]
         l.dyo_kdx_build.restype = C.c_int; l.dyo_kdx_build.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, P, P, C.c_uint32]
+        l.dyo_align_match.restype = C.c_int
+        l.dyo_align_match.argtypes = [P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, P, P]
         l.dyo_ibf_free.argtypes = [P]
         l.dyo_ibf_info.argtypes = [P, P]
         l.dyo_ibf_query.restype = C.c_int; l.dyo_ibf_query.argtypes = [P, P, P, C.c_uint32, C.c_uint16, P]
@@ -134,3 +136,11 @@ def map_batch(index, ibf, codes, offs, error_rate, strata_rate=0.0, sensitivity=
     finally:
         lib().dyo_result_free(h)
     return reads, matches, cigars, {"items": int(stats[0]), "raw_matches": int(stats[1])}
+
+
+def align_match(contig, read, errors):
+    """oracle alignMatch (reference src/mapper_aligner.h:143-236): (cigar ops as (len << 4) | op, clip begin, clip end)."""
+    contig = np.ascontiguousarray(contig, dtype=np.uint8); read = np.ascontiguousarray(read, dtype=np.uint8)
+    out = np.zeros(64, np.uint32); cb = C.c_int(0); ce = C.c_int(0)
+    k = lib().dyo_align_match(contig.ctypes.data, contig.size, read.ctypes.data, read.size, errors, out.ctypes.data, 64, C.byref(cb), C.byref(ce))
+    return out[:k].tolist(), cb.value, ce.value

@@ -609,6 +609,35 @@ def test_cli_kmer_direct_equals_oracle_cli(product_build, oracle_build, tmp_path
     assert sam_records(a) == sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.t1.sam"))     # a filter without false negatives changes nothing
 
 
+@pytest.mark.parametrize("ftype", ["bloom", "kmer_direct"])
+def test_update_filter_equals_fresh_build(product_build, dy, ctx, ob, tmp_path, ftype):
+    """dream_yara_update_filter (clearBins + re-add, reference src/d_update_filter.cpp:187-240): a bit belongs to one
+    (position, bin), so updating bins 2 and 5 must give exactly the filter built from the new genome set."""
+    rng = np.random.default_rng(31)
+    bins, k = 70, 9
+    old = [rng.integers(0, 4, 4000, dtype=np.uint8) for _ in range(bins)]
+    new = [g.copy() for g in old]
+    new[2] = rng.integers(0, 4, 5000, dtype=np.uint8); new[5] = rng.integers(0, 4, 300, dtype=np.uint8); new[69] = rng.integers(0, 4, 1000, dtype=np.uint8)
+    def build(path, genomes):
+        offs = np.zeros(bins + 1, np.uint64); offs[1:] = np.cumsum([g.size for g in genomes])
+        if ftype == "bloom": ob.build_filter(path, bins, 3, k, 1 << 22, np.concatenate(genomes), offs)
+        else: ob.build_direct_filter(path, bins, k, np.concatenate(genomes), offs)
+    mine, want = str(tmp_path / "mine.filter"), str(tmp_path / "want.filter")
+    build(mine, old); build(want, new)
+    assert open(mine, "rb").read() != open(want, "rb").read()
+    files = []
+    for b in (2, 5, 69):
+        p = tmp_path / ("%d.fna" % b)
+        p.write_text(">c\n" + "".join("ACGT"[c] for c in new[b]) + "\n")
+        files.append(str(p))
+    subprocess.check_call([os.path.join(product_build, "dream_yara_update_filter"), "-ft", ftype, mine] + files)
+    assert open(mine, "rb").read() == open(want, "rb").read()
+    # out-of-range bin: refused like the reference (exit 1), file untouched
+    bad = tmp_path / "70.fna"; bad.write_text(">c\nACGTACGTACGT\n")
+    assert subprocess.call([os.path.join(product_build, "dream_yara_update_filter"), "-ft", ftype, mine, str(bad)], stderr=subprocess.DEVNULL) == 1
+    assert open(mine, "rb").read() == open(want, "rb").read()
+
+
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
 @pytest.mark.parametrize("strata", [0.0, 0.02])
 def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata):
