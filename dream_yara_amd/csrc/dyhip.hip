@@ -319,7 +319,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             V.optLibLength = p->library_length; V.optLibDev = p->library_dev; V.verify = p->verify_matches;
             V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
             hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V);
-            hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(64), 0, st, V);
+            hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(1024), 0, st, V);
             if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
             if (p->verify_matches && nItems)
             {
@@ -347,7 +347,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                 ctx->scanTmp.reserve(tb + 64);
                 HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
             }
-            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->complexList.as<u32>(), complexCount);
+            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount);
             hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
         }
         HIP_CHECK(hipGetLastError());

@@ -224,21 +224,41 @@ __device__ __forceinline__ double peLibraryProb(const RawMatch & one, const RawM
     return e > 0.001 ? e : 0.001;
 }
 
-// ---- stage 2: library statistics of one bin (one wavefront per bin) -------------------------------------------------
-__global__ __launch_bounds__(64) void k_pe_library(PeView V)
+// ---- stage 2: library statistics of one bin (one 1024-thread block per bin) ----------------------------------------------
+// out[pos] = value for the threads that want it, in thread order, pos continuing from `count` (block-wide, ordered)
+__device__ __forceinline__ u32 blockPushOrdered(bool want, u32 & count, u32 * waveTotals /* LDS, 16 */)
 {
-    const u32 bin = blockIdx.x, lane = threadIdx.x;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const u64 mask = __ballot(want);
+    if (lane == 0) waveTotals[wave] = (u32)__popcll(mask);
+    __syncthreads();
+    u32 before = 0, total = 0;
+    for (u32 w = 0; w < nWaves; ++w) { const u32 t = waveTotals[w]; if (w < wave) before += t; total += t; }
+    const u32 slot = count + before + (u32)__popcll(mask & ((1ull << lane) - 1));
+    count += total;
+    __syncthreads();
+    return slot;
+}
+
+__global__ __launch_bounds__(1024) void k_pe_library(PeView V)
+{
+    __shared__ u32 hist[2048];
+    __shared__ u32 waveTotals[16];
+    __shared__ u32 sel[4];          // radix select state: prefix value, remaining rank
+    __shared__ float chunk[4096];
+    const u32 bin = blockIdx.x, tid = threadIdx.x, nThreads = blockDim.x;
     if (bin >= V.nBins) return;
     const u32 b0 = V.binStart[bin], Pc = (V.binStart[bin + 1] - b0) / 2;
     PeLibrary L; L.length = 0; L.dev = 0; L.pairing = 1; L.nLens = 0;
     if (!V.optLibLength || !V.optLibDev)
     {
         u32 * lens = V.libLens + b0;
-        u32 * idx = V.libIdx + b0;
+        u32 * kept = V.libIdx + b0;
+        // unique, properly oriented pairs in pair order (reference src/mapper.h:931-947)
         u32 cnt = 0;
-        for (u32 base = 0; base < Pc; base += 64)
+        for (u32 base = 0; base < Pc; base += nThreads)
         {
-            const u32 j = base + lane;
+            const u32 j = base + tid;
             bool take = false; u32 len = 0;
             if (j < Pc)
             {
@@ -249,50 +269,87 @@ __global__ __launch_bounds__(64) void k_pe_library(PeView V)
                     if (fm.contig == sm.contig && peOrientationProper(fm, sm)) { take = true; len = peLibraryLength(fm, sm); }
                 }
             }
-            const u32 slot = wavePush(take, lane, cnt);
+            const u32 slot = blockPushOrdered(take, cnt, waveTotals);
             if (take) lens[slot] = len;
         }
-        waveFence();
+        __threadfence_block(); __syncthreads();
         if (cnt == 0) L.pairing = 0;
         else
         {
-            for (u32 i = lane; i < cnt; i += 64) idx[i] = i;
-            waveFence();
-            waveSort(idx, cnt, lane, [&](u32 a, u32 b) { return lens[a] < lens[b] || (lens[a] == lens[b] && a < b); });
-            const u32 median = lens[idx[cnt / 2]];
-            waveFence();
-            // removeIf(> 6.0 * median), order kept
-            u32 kept = 0;
-            for (u32 base = 0; base < cnt; base += 64)
+            // median = element cnt/2 of the sorted lengths (nthElement, :952): radix select, 11 + 11 + 10 bits
+            if (tid == 0) { sel[0] = 0; sel[1] = cnt / 2; }
+            const u32 shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+            u32 prefixMask = 0;
+            for (u32 pass = 0; pass < 3; ++pass)
             {
-                const u32 i = base + lane;
+                for (u32 i = tid; i < 2048; i += nThreads) hist[i] = 0;
+                __syncthreads();
+                const u32 prefix = sel[0];
+                for (u32 i = tid; i < cnt; i += nThreads)
+                {
+                    const u32 v = lens[i];
+                    if ((v & prefixMask) == prefix) atomicAdd(&hist[(v >> shifts[pass]) & ((1u << widths[pass]) - 1)], 1u);
+                }
+                __syncthreads();
+                if (tid == 0)
+                {
+                    u32 rank = sel[1], d = 0;
+                    for (;; ++d) { if (rank < hist[d]) break; rank -= hist[d]; }
+                    sel[0] = prefix | (d << shifts[pass]); sel[1] = rank;
+                }
+                prefixMask |= ((1u << widths[pass]) - 1) << shifts[pass];
+                __syncthreads();
+            }
+            const u32 median = sel[0];
+            // removeIf(> 6.0 * median), order kept (:953)
+            u32 nKept = 0;
+            for (u32 base = 0; base < cnt; base += nThreads)
+            {
+                const u32 i = base + tid;
                 const u32 v = i < cnt ? lens[i] : 0;
                 const bool keep = i < cnt && !((double)v > 6.0 * (double)median);
-                const u32 slot = wavePush(keep, lane, kept);
-                waveFence();
-                if (keep) idx[slot] = v;          // idx now holds the kept values in order
-                waveFence();
+                const u32 slot = blockPushOrdered(keep, nKept, waveTotals);
+                if (keep) kept[slot] = v;
             }
-            if (kept == 0) L.pairing = 0;
+            __threadfence_block(); __syncthreads();
+            if (nKept == 0) L.pairing = 0;
             else
             {
-                // sequential float arithmetic in pair order, like the single-threaded reference
-                u32 sum = 0;
-                for (u32 i = 0; i < kept; ++i) sum += idx[i];
-                float mean = (float)sum / (float)kept; if (!(mean > 1.0f)) mean = 1.0f;
+                // the sum is an unsigned accumulate (order-free); the squared deviations are summed in float in pair order like
+                // the single-threaded reference (:959-967): chunks are staged in LDS by the block, one thread walks them
+                if (tid == 0) sel[2] = 0;
+                __syncthreads();
+                u32 part = 0;
+                for (u32 i = tid; i < nKept; i += nThreads) part += kept[i];
+                atomicAdd(&sel[2], part);
+                __syncthreads();
+                float mean = (float)sel[2] / (float)nKept; if (!(mean > 1.0f)) mean = 1.0f;
                 float sq = 0.0f;
-                for (u32 i = 0; i < kept; ++i) { const float d = (float)idx[i] - mean; sq += d * d; }
-                float dev = sqrtf(sq / (float)kept); if (!(dev > 1.0f)) dev = 1.0f;
-                L.length = (u32)mean; L.dev = (u32)dev; L.nLens = kept;
+                for (u32 base = 0; base < nKept; base += 4096)
+                {
+                    const u32 m = min(4096u, nKept - base);
+                    for (u32 i = tid; i < m; i += nThreads) chunk[i] = (float)kept[base + i];
+                    __syncthreads();
+                    if (tid == 0) for (u32 i = 0; i < m; ++i) { const float d = chunk[i] - mean; sq += d * d; }
+                    __syncthreads();
+                }
+                if (tid == 0)
+                {
+                    float dev = sqrtf(sq / (float)nKept); if (!(dev > 1.0f)) dev = 1.0f;
+                    L.length = (u32)mean; L.dev = (u32)dev; L.nLens = nKept;
+                }
             }
         }
     }
-    if (L.pairing)
+    if (tid == 0)
     {
-        if (V.optLibLength) L.length = V.optLibLength;
-        if (V.optLibDev) L.dev = V.optLibDev;
+        if (L.pairing)
+        {
+            if (V.optLibLength) L.length = V.optLibLength;
+            if (V.optLibDev) L.dev = V.optLibDev;
+        }
+        V.lib[bin] = L;
     }
-    if (lane == 0) V.lib[bin] = L;
 }
 
 // findProperMates (reference src/bits_matches.h:819-867): [first,last) in the mate's coordinate-sorted unique matches
@@ -552,18 +609,62 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
 }
 
 // ---- stage 5: routing + final per-read aggregation ------------------------------------------------------------------
-__global__ void k_pe_route(FinalizeArgs A, PeView V, u32 * __restrict__ list, u32 * __restrict__ listCount)
+// One thread per read.  Unmapped reads and — the bulk of a real batch — reads whose whole evidence is ONE entry (a single raw
+// match, or a single rescued mate, in the only bin the pair selected) are finished here; the child and main mappers' sorts
+// and compactions are identities on one entry.  A primary that needs the alignment DP, and every read with more entries,
+// goes to the list of k_pe_finalize.
+__global__ void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, u32 * __restrict__ list, u32 * __restrict__ listCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
-    if (read >= A.nReads) return;
-    const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
-    if (n == 0 && !V.readHasRescue[read])
+    bool complex = false;
+    if (read < A.nReads)
     {
-        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
-        A.out[read] = ro;
-        return;
+        const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+        const bool hasRescue = V.readHasRescue[read] != 0;
+        if (n == 0 && !hasRescue)
+        {
+            ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
+            A.out[read] = ro;
+        }
+        else
+        {
+            complex = true;
+            u32 nSel = 0, bin = 0;
+            for (u32 w = 0; w < V.W; ++w)
+            {
+                const u64 m = V.masks[(size_t)read * V.W + w];
+                if (m) bin = w * 64 + (u32)(__ffsll((long long)m) - 1);
+                nSel += (u32)__popcll(m);
+            }
+            if (nSel == 1 && n <= 1)
+            {
+                const PeItem it = V.items[peFindItem(V, read, bin)];
+                RawMatch prim; bool ok = false;
+                if (n == 1) { prim = A.gp[s0]; ok = prim.bin == bin && it.primary == 0; }
+                else if (it.rescued) { prim = it.mate; ok = true; }
+                if (ok)
+                {
+                    const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+                    bool plain = prim.errors == 0 || (prim.errors == 1 && prim.len == readLen);
+                    if (!plain && prim.errors == 2 && prim.len == readLen && readLen >= 8)
+                    {
+                        const BinDesc & bd = A.bins[bin];
+                        const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + prim.contig] + prim.begin;
+                        plain = alignIsUngapped2(ctg, (prim.strand ? A.readSeqsRc : A.readSeqs) + A.readOffs[read], (int)readLen);
+                    }
+                    if (plain)
+                    {
+                        ReadOut ro; initReadOut(ro, mStart[read], read * A.cigarStride);
+                        A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1;
+                        ro.paired = it.paired ? 1 : 0; ro.pairProb = it.paired ? it.prob : 0.0;
+                        writeSingleMatch(A, read, ro, prim);
+                        complex = false;
+                    }
+                }
+            }
+        }
     }
-    list[atomicAdd(listCount, 1u)] = read;
+    waveAppend(complex, read, list, listCount);
 }
 
 __global__ __launch_bounds__(256) void k_pe_finalize(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart)

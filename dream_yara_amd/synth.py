@@ -103,3 +103,38 @@ def reads_fasta(path, codes, offs, prefix="read"):
             f.write(b">%s.%d\n" % (prefix.encode(), i))
             f.write(ALPHABET[codes[int(offs[i]):int(offs[i + 1])]].tobytes())
             f.write(b"\n")
+
+
+def simulate_pairs(genomes, n_pairs, read_len, seed, insert_mean=400.0, insert_sd=40.0, sub_lo=0.001, sub_hi=0.010):
+    """FR pairs: fragment ~ N(mean, sd) from a uniform bin/position, first mate = fragment start on
+    the forward strand, second mate = reverse complement of the fragment end; half of the pairs are flipped.  Returns
+    (codes, offs, truth) in the batch layout of a paired run: first mates [0,P), second mates [P,2P)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    n_bins = len(genomes)
+    bins = rng.integers(0, n_bins, size=n_pairs, dtype=np.int64)
+    lens = np.array([g.size for g in genomes], dtype=np.int64)
+    frag = np.clip(np.rint(rng.normal(insert_mean, insert_sd, n_pairs)).astype(np.int64), read_len + 1, None)
+    starts = (rng.random(n_pairs) * (lens[bins] - frag - 1)).astype(np.int64)
+    m1 = np.empty((n_pairs, read_len), dtype=np.uint8)
+    m2 = np.empty((n_pairs, read_len), dtype=np.uint8)
+    ar = np.arange(read_len)[None, :]
+    for b in range(n_bins):
+        sel = np.nonzero(bins == b)[0]
+        if sel.size:
+            g = genomes[b]
+            m1[sel] = g[starts[sel][:, None] + ar]
+            tail = g[(starts[sel] + frag[sel] - read_len)[:, None] + ar]
+            m2[sel] = np.where(tail[:, ::-1] < 4, 3 - tail[:, ::-1], tail[:, ::-1])
+    flip = rng.random(n_pairs) < 0.5          # the fragment came from the reverse strand: the mates swap roles
+    a = np.where(flip[:, None], m2, m1); b2 = np.where(flip[:, None], m1, m2)
+    rate = np.linspace(sub_lo, sub_hi, read_len)[None, :]
+    out = []
+    for m in (a, b2):
+        hit = rng.random((n_pairs, read_len)) < rate
+        shift = rng.integers(1, 4, size=(n_pairs, read_len), dtype=np.uint8)
+        out.append(np.where(hit, (m + shift) & 3, m).astype(np.uint8))
+    codes = np.ascontiguousarray(np.concatenate(out, axis=0)).reshape(-1)
+    offs = (np.arange(2 * n_pairs + 1, dtype=np.uint64) * np.uint64(read_len))
+    truth = np.zeros(n_pairs, dtype=[("bin", "<u4"), ("start", "<i8"), ("frag", "<i8"), ("flip", "u1")])
+    truth["bin"], truth["start"], truth["frag"], truth["flip"] = bins, starts, frag, flip
+    return codes, offs, truth
