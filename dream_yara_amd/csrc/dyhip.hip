@@ -222,7 +222,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         for (;;)
         {
             ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
-            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 32, st));
+            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 64, st));
             HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
             MatchSink sink; sink.debugFlags = getenv("DY_DEBUG_EXTEND") ? (u32)atoi(getenv("DY_DEBUG_EXTEND")) : 0; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
             sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
@@ -318,7 +318,10 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             V.lib = ctx->peLib.as<PeLibrary>(); V.libLens = ctx->peLens.as<u32>(); V.libIdx = ctx->peIdx.as<u32>();
             V.optLibLength = p->library_length; V.optLibDev = p->library_dev; V.verify = p->verify_matches;
             V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
-            hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V);
+            ctx->dpList.reserve((size_t)nReads * 4 + 64);         // reads with more than one raw match (list of k_pe_child)
+            u32 * childCount = ctx->counters.as<u32>() + 8;
+            hipLaunchKernelGGL(k_pe_child_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
+            hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
             hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(1024), 0, st, V);
             if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
             if (p->verify_matches && nItems)
@@ -347,7 +350,11 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                 ctx->scanTmp.reserve(tb + 64);
                 HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->peMCounts.as<u32>(), ctx->peMStart.as<u32>(), (int)(nReads + 1), st));
             }
-            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount);
+            ctx->alignList.reserve((size_t)nReads * 4 + 64);
+            u32 * peAlignCount = ctx->counters.as<u32>() + 9;
+            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount,
+                               ctx->alignList.as<u32>(), peAlignCount);
+            hipLaunchKernelGGL(k_pe_align_single, dim3(1024), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
             hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
         }
         HIP_CHECK(hipGetLastError());
@@ -1093,7 +1100,7 @@ int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const 
         HIP_CHECK(hipMemcpyAsync(ctx->binOrderRank.p, rank.data(), (size_t)nBins * 4, hipMemcpyHostToDevice, st));
         ctx->counters.reserve(64);
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
-        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 32, st));
+        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 64, st));
         HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
         HIP_CHECK(hipEventRecord(ctx->ev[5], st));
         if (nPool)

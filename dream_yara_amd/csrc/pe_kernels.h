@@ -139,13 +139,35 @@ __device__ inline ChildSeg peChildPasses(const RawMatch * E, const u32 * idxA, u
 }
 
 // ---- stage 1: per read, per bin -> unique matches in coordinate order + SE rank ------------------------------------
-__global__ __launch_bounds__(256) void k_pe_child(FinalizeArgs A, PeView V)
+// One thread per read: a read with a single raw match is its own child result; reads with more go to the list of k_pe_child.
+__global__ void k_pe_child_simple(FinalizeArgs A, PeView V, u32 * __restrict__ list, u32 * __restrict__ listCount)
+{
+    const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
+    bool more = false;
+    if (read < A.nReads)
+    {
+        const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+        if (n == 1)
+        {
+            const RawMatch a = A.gp[s0];
+            V.u2[s0] = a;
+            PeItem & it = V.items[peFindItem(V, read, a.bin)];
+            it.u2Off = s0; it.nU2 = 1; it.nOpt = 1; it.nSet = 1; it.primary = 0; it.minErr = a.errors;
+        }
+        more = n > 1;
+    }
+    waveAppend(more, read, list, listCount);
+}
+
+__global__ __launch_bounds__(256) void k_pe_child(FinalizeArgs A, PeView V, const u32 * __restrict__ list, const u32 * __restrict__ listCount)
 {
     const u32 lane = threadIdx.x & 63;
     const u32 gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 nWaves = (gridDim.x * blockDim.x) >> 6;
-    for (u32 read = gwave; read < A.nReads; read += nWaves)
+    const u32 nList = *listCount;
+    for (u32 li = gwave; li < nList; li += nWaves)
     {
+        const u32 read = list[li];
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
         if (n == 0) continue;
         const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
@@ -613,10 +635,11 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
 // match, or a single rescued mate, in the only bin the pair selected) are finished here; the child and main mappers' sorts
 // and compactions are identities on one entry.  A primary that needs the alignment DP, and every read with more entries,
 // goes to the list of k_pe_finalize.
-__global__ void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, u32 * __restrict__ list, u32 * __restrict__ listCount)
+__global__ void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, u32 * __restrict__ list, u32 * __restrict__ listCount,
+                           u32 * __restrict__ alignList, u32 * __restrict__ alignCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
-    bool complex = false;
+    bool complex = false, align = false;
     if (read < A.nReads)
     {
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
@@ -660,11 +683,40 @@ __global__ void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mS
                         writeSingleMatch(A, read, ro, prim);
                         complex = false;
                     }
+                    else if (readLen <= THREAD_DP_MAX_LEN && prim.errors <= THREAD_DP_MAX_E) { complex = false; align = true; }
                 }
             }
         }
     }
     waveAppend(complex, read, list, listCount);
+    waveAppend(align, read, alignList, alignCount);
+}
+
+// Single-entry reads whose primary needs the alignment DP (thread-level DP, all lanes busy)
+__global__ __launch_bounds__(256) void k_pe_align_single(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, const u32 * __restrict__ alignList,
+                                                         const u32 * __restrict__ alignCount)
+{
+    const u32 nList = *alignCount;
+    for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
+    {
+        const u32 read = alignList[li];
+        const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+        const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+        u32 bin = 0;
+        for (u32 w = 0; w < V.W; ++w) { const u64 m = V.masks[(size_t)read * V.W + w]; if (m) bin = w * 64 + (u32)(__ffsll((long long)m) - 1); }
+        const PeItem it = V.items[peFindItem(V, read, bin)];
+        RawMatch a = n == 1 ? A.gp[s0] : it.mate;
+        ReadOut ro; initReadOut(ro, mStart[read], read * A.cigarStride);
+        const BinDesc & bd = A.bins[bin];
+        const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+        int cb, ce;
+        const u32 nc = alignMatchThread(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
+                                        A.cigars + ro.cigarBegin, A.cigarStride, cb, ce);
+        ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+        a.begin += (u32)cb; a.len = (u16)ce;
+        ro.paired = it.paired ? 1 : 0; ro.pairProb = it.paired ? it.prob : 0.0;
+        writeSingleMatch(A, read, ro, a);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_pe_finalize(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart)
