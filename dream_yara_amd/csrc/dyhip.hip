@@ -75,6 +75,8 @@ struct dy_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    hipStream_t side[2] = {};          // K4's list kernels are latency-bound on a handful of waves each: they run side by side
+    hipEvent_t evFork = nullptr, evJoin[2] = {};
     dy_map_stats stats = {};
     bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
@@ -293,14 +295,22 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             u32 * alignCount = ctx->counters.as<u32>() + 4;
             ctx->smallList.reserve((size_t)nReads * 4 + 64);
             u32 * smallCount = ctx->counters.as<u32>() + 5;
-            hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
+            hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
                                ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
             ctx->dpList.reserve((size_t)nReads * 4 + 64);
             u32 * dpCount = ctx->counters.as<u32>() + 6;
+            // the three list kernels touch disjoint reads: fork after the routing kernel, join before the stage ends
+            HIP_CHECK(hipEventRecord(ctx->evFork, st));
+            HIP_CHECK(hipStreamWaitEvent(ctx->side[0], ctx->evFork, 0));
+            HIP_CHECK(hipStreamWaitEvent(ctx->side[1], ctx->evFork, 0));
+            hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
+            hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa);
+            HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
+            HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
             hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount);
             hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->dpList.as<u32>(), dpCount);
-            hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, st, fa, ctx->smallList.as<u32>(), smallCount);
-            hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, st, fa);
+            HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
+            HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
         }
         else
         {
@@ -320,7 +330,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
             ctx->dpList.reserve((size_t)nReads * 4 + 64);         // reads with more than one raw match (list of k_pe_child)
             u32 * childCount = ctx->counters.as<u32>() + 8;
-            hipLaunchKernelGGL(k_pe_child_simple, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
+            hipLaunchKernelGGL(k_pe_child_simple, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
             hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
             hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(1024), 0, st, V);
             if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
@@ -352,7 +362,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             }
             ctx->alignList.reserve((size_t)nReads * 4 + 64);
             u32 * peAlignCount = ctx->counters.as<u32>() + 9;
-            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 255) / 256), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount,
+            hipLaunchKernelGGL(k_pe_route, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount,
                                ctx->alignList.as<u32>(), peAlignCount);
             hipLaunchKernelGGL(k_pe_align_single, dim3(1024), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
             hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
@@ -408,6 +418,9 @@ int dy_ctx_create(int device, dy_ctx ** out)
         c->device = device;
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         for (auto & e : c->ev) HIP_CHECK(hipEventCreate(&e));
+        for (auto & q : c->side) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        for (auto & e : c->evJoin) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         *out = c.release();
     });
 }
@@ -418,6 +431,9 @@ void dy_ctx_free(dy_ctx * ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (auto & e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    for (auto & q : ctx->side) if (q) (void)hipStreamDestroy(q);
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    for (auto & e : ctx->evJoin) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -726,26 +726,44 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
 __device__ __forceinline__ void writeSingleMatch(const FinalizeArgs & A, u32 read, ReadOut & ro, const RawMatch & a)
 {
     OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
-    A.outSet[(size_t)ro.setBegin] = om;
+    if (!(A.debugFlags & 4)) A.outSet[(size_t)ro.setBegin] = om;
     ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
     ro.mapped = om.length != 0; ro.bestCount = 1; ro.subCount = 0;
-    A.out[read] = ro;
+    if (!(A.debugFlags & 16)) A.out[read] = ro;
 }
 
-// list[count++] = value for the lanes that want it: one atomic per wavefront and list
-__device__ __forceinline__ void waveAppend(bool want, u32 value, u32 * __restrict__ list, u32 * __restrict__ count)
+// list[count++] = value for the threads that want it, NL lists at once, ONE global atomic per block and list: same-address
+// atomics are served one at a time (~10 ns each on this chip), so with one per wavefront a million-thread routing kernel
+// spends 0.3 ms queueing for its list counters.  Every thread of the block must call this (it synchronises).
+template <int NL>
+__device__ __forceinline__ void blockAppend(const bool (&want)[NL], u32 value, u32 * const (&lists)[NL], u32 * const (&counts)[NL])
 {
-    const u64 mask = __ballot(want);
-    if (!mask) return;
-    const u32 lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    u32 base = 0;
-    if ((int)lane == leader) base = atomicAdd(count, (u32)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (want) list[base + (u32)__popcll(mask & ((1ull << lane) - 1))] = value;
+    __shared__ u32 waveOff[NL][16];
+    __shared__ u32 blockBase[NL];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+    u64 mask[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+    {
+        mask[l] = __ballot(want[l]);
+        if (lane == 0) waveOff[l][wave] = (u32)__popcll(mask[l]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NL)
+    {
+        const u32 l = threadIdx.x;
+        u32 total = 0;
+        for (u32 w = 0; w < nWaves; ++w) { const u32 t = waveOff[l][w]; waveOff[l][w] = total; total += t; }
+        blockBase[l] = total ? atomicAdd(counts[l], total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+        if (want[l]) lists[l][blockBase[l] + waveOff[l][wave] + (u32)__popcll(mask[l] & ((1ull << lane) - 1))] = value;
+    __syncthreads();
 }
 
-__global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount,
+__global__ __launch_bounds__(1024) void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount,
                                   u32 * __restrict__ alignList, u32 * __restrict__ alignCount, u32 * __restrict__ smallList, u32 * __restrict__ smallCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
@@ -765,7 +783,8 @@ __global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList
                 const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
                 if (!gapped)
                 {
-                    A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1;
+                    if (!(A.debugFlags & 8)) A.cigars[ro.cigarBegin] = (readLen << 4) | 0;
+                    ro.cigarLen = 1;
                     writeSingleMatch(A, read, ro, a);
                     route = 0;
                 }
@@ -776,9 +795,10 @@ __global__ void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList
                 route = 2;
         }
     }
-    waveAppend(route == 1, read, alignList, alignCount);
-    waveAppend(route == 2, read, smallList, smallCount);
-    waveAppend(route == 3, read, complexList, complexCount);
+    const bool want[3] = {route == 1, route == 2, route == 3};
+    u32 * const lists[3] = {alignList, smallList, complexList};
+    u32 * const counts[3] = {alignCount, smallCount, complexCount};
+    blockAppend<3>(want, read, lists, counts);
 }
 
 // First pass over the align list: a 2-substitution match needs no DP when alignIsUngapped2 holds; the rest goes to dpList.
@@ -811,7 +831,10 @@ __global__ __launch_bounds__(256) void k_align_check(FinalizeArgs A, const u32 *
                 }
             }
         }
-        waveAppend(needDp, read, dpList, dpCount);
+        const bool want[1] = {needDp};
+        u32 * const lists[1] = {dpList};
+        u32 * const counts[1] = {dpCount};
+        blockAppend<1>(want, read, lists, counts);
     }
 }
 

@@ -608,6 +608,36 @@ __device__ __forceinline__ void flushWaveMatches(const ItemState & st, u32 read,
     }
 }
 
+// same, one pool reservation per BLOCK (same-address atomics are served one at a time; every thread of the block must call this)
+__device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read, const MatchSink & sink, u32 lane)
+{
+    __shared__ u32 waveOff[16];
+    __shared__ u32 blockBase;
+    const u32 wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
+    const u32 cnt = st.nbuf;
+    u32 incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+    if (lane == 63) waveOff[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        u32 total = 0;
+        for (u32 w = 0; w < nWaves; ++w) { const u32 t = waveOff[w]; waveOff[w] = total; total += t; }
+        blockBase = total ? atomicAdd(sink.poolCount, total) : 0;
+    }
+    __syncthreads();
+    const u32 first = blockBase + waveOff[wave] + incl - cnt;
+    if (cnt >= 1)
+    {
+        if (first < sink.poolCap) { sink.pool[first] = st.buf0; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+    if (cnt >= 2)
+    {
+        if (first + 1 < sink.poolCap) { sink.pool[first + 1] = st.buf1; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? DY_K3_WAVES : 1, NW <= 2 ? DY_K3_WAVES : 8))) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
                                                 u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? D
     const bool valid = item < nItems;
     if (valid) { read = itemRead[item]; bin = itemBin[item]; }
     extendEasyItem<NW>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardCount, hardList, st, valid);
-    flushWaveMatches(st, read, sink, lane);
+    flushBlockMatches(st, read, sink, lane);
 }
 
 // The re-seeded items listed by k_extend (the list length is only known on the device).

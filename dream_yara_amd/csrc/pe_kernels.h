@@ -140,7 +140,7 @@ __device__ inline ChildSeg peChildPasses(const RawMatch * E, const u32 * idxA, u
 
 // ---- stage 1: per read, per bin -> unique matches in coordinate order + SE rank ------------------------------------
 // One thread per read: a read with a single raw match is its own child result; reads with more go to the list of k_pe_child.
-__global__ void k_pe_child_simple(FinalizeArgs A, PeView V, u32 * __restrict__ list, u32 * __restrict__ listCount)
+__global__ __launch_bounds__(1024) void k_pe_child_simple(FinalizeArgs A, PeView V, u32 * __restrict__ list, u32 * __restrict__ listCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
     bool more = false;
@@ -156,7 +156,10 @@ __global__ void k_pe_child_simple(FinalizeArgs A, PeView V, u32 * __restrict__ l
         }
         more = n > 1;
     }
-    waveAppend(more, read, list, listCount);
+    const bool want[1] = {more};
+    u32 * const lists[1] = {list};
+    u32 * const counts[1] = {listCount};
+    blockAppend<1>(want, read, lists, counts);
 }
 
 __global__ __launch_bounds__(256) void k_pe_child(FinalizeArgs A, PeView V, const u32 * __restrict__ list, const u32 * __restrict__ listCount)
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
 // match, or a single rescued mate, in the only bin the pair selected) are finished here; the child and main mappers' sorts
 // and compactions are identities on one entry.  A primary that needs the alignment DP, and every read with more entries,
 // goes to the list of k_pe_finalize.
-__global__ void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, u32 * __restrict__ list, u32 * __restrict__ listCount,
+__global__ __launch_bounds__(1024) void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, u32 * __restrict__ list, u32 * __restrict__ listCount,
                            u32 * __restrict__ alignList, u32 * __restrict__ alignCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
@@ -688,8 +691,10 @@ __global__ void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mS
             }
         }
     }
-    waveAppend(complex, read, list, listCount);
-    waveAppend(align, read, alignList, alignCount);
+    const bool want[2] = {complex, align};
+    u32 * const lists[2] = {list, alignList};
+    u32 * const counts[2] = {listCount, alignCount};
+    blockAppend<2>(want, read, lists, counts);
 }
 
 // Single-entry reads whose primary needs the alignment DP (thread-level DP, all lanes busy)
