@@ -59,6 +59,7 @@ struct DevBuf
         cap = want;
     }
     template <typename T> T * as() const { return (T *)p; }
+    void moveTo(DevBuf & o) { if (o.p) (void)hipFree(o.p); o.p = p; o.cap = cap; p = nullptr; cap = 0; }
 };
 
 int deviceCount()
@@ -85,10 +86,29 @@ struct dy_ctx
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList;
     size_t poolCap = 0;
+    DevBuf spare[6];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
     u32 lastRaw = 0; bool rawValid = false;
 };
+
+// result buffers are recycled through the context: take the smallest spare that is large enough, else allocate
+static void takeBuffer(dy_ctx * ctx, DevBuf & d, size_t bytes)
+{
+    int best = -1;
+    for (int i = 0; i < 6; ++i)
+        if (ctx->spare[i].p && ctx->spare[i].cap >= bytes && (best < 0 || ctx->spare[i].cap < ctx->spare[best].cap)) best = i;
+    if (best >= 0) ctx->spare[best].moveTo(d);
+    else d.reserve(bytes);
+}
+static void giveBuffer(dy_ctx * ctx, DevBuf & d)
+{
+    if (!d.p) return;
+    int slot = -1;
+    for (int i = 0; i < 6; ++i) if (!ctx->spare[i].p) { slot = i; break; }
+    if (slot < 0) { slot = 0; for (int i = 1; i < 6; ++i) if (ctx->spare[i].cap < ctx->spare[slot].cap) slot = i; if (ctx->spare[slot].cap >= d.cap) return; }
+    d.moveTo(ctx->spare[slot]);
+}
 
 struct dy_ibf
 {
@@ -103,7 +123,7 @@ struct dy_reads
     dy_ctx * ctx = nullptr;
     u32 n = 0; u64 totalBases = 0; u32 maxLen = 0; u32 minLen = 0;
     DevBuf seqs, seqsRc, offs, masks;
-    std::vector<u32> lens;   // host copy of the read lengths (MAPQ needs them)
+    std::shared_ptr<std::vector<u32>> lens = std::make_shared<std::vector<u32>>();   // host copy of the read lengths (MAPQ needs them); shared with results
     u32 maskW = 0;       // words per read currently held in masks (0 = none)
     u32 maskBins = 0;
 };
@@ -136,7 +156,7 @@ struct dy_result
 {
     dy_ctx * ctx = nullptr;
     u32 nReads = 0; u32 nPool = 0; u32 cigarStride = 0; size_t setCap = 0;
-    std::vector<u32> readLens;
+    std::shared_ptr<const std::vector<u32>> readLens;
     DevBuf out, outSet, cigars;
     bool fetched = false;
     std::vector<dy_read_result> reads;
@@ -276,7 +296,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         res->setCap = setCap;
         ctx->marr.reserve(setCap * sizeof(RawMatch) + 64);
         ctx->maux.reserve(setCap * 2 * 4 + 64);
-        res->outSet.reserve(setCap * sizeof(OutMatch) + 64);
+        takeBuffer(ctx, res->outSet, setCap * sizeof(OutMatch) + 64);
         const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
         const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
         ctx->dp.reserve(dpStride * finWaves + 64);
@@ -386,8 +406,8 @@ static std::unique_ptr<dy_result> makeResult(dy_ctx * ctx, const dy_reads * read
 {
     std::unique_ptr<dy_result> res(new dy_result);
     res->ctx = ctx; res->nReads = reads->n; res->cigarStride = 2 * maxMatchErr + 1;
-    res->out.reserve((size_t)reads->n * sizeof(ReadOut) + 64);
-    res->cigars.reserve((size_t)reads->n * res->cigarStride * 4 + 64);
+    takeBuffer(ctx, res->out, (size_t)reads->n * sizeof(ReadOut) + 64);
+    takeBuffer(ctx, res->cigars, (size_t)reads->n * res->cigarStride * 4 + 64);
     return res;
 }
 
@@ -640,7 +660,7 @@ int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, u
             u64 l = offs[i + 1] - offs[i];
             if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");      // reference src/mapper.h:453-454
             mx = std::max<u32>(mx, (u32)l); mn = std::min<u32>(mn, (u32)l);
-            r->lens.push_back((u32)l);
+            r->lens->push_back((u32)l);
         }
         r->maxLen = mx; r->minLen = n_reads ? mn : 0;
         r->seqs.reserve(r->totalBases + 64);
@@ -849,8 +869,8 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         u32 maxMatchErr = maxErr;
         if (p->paired && p->verify_matches) { u32 mi = (u32)((float)reads->maxLen * p->indel_rate); maxMatchErr = std::min<u32>(MAX_ERRORS, maxErr + std::min<u32>(mi, MAX_ERRORS)); }
         res->ctx = ctx; res->nReads = nReads; res->cigarStride = 2 * maxMatchErr + 1;
-        res->out.reserve((size_t)nReads * sizeof(ReadOut) + 64);
-        res->cigars.reserve((size_t)nReads * res->cigarStride * 4 + 64);
+        takeBuffer(ctx, res->out, (size_t)nReads * sizeof(ReadOut) + 64);
+        takeBuffer(ctx, res->cigars, (size_t)nReads * res->cigarStride * 4 + 64);
         ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
         if (nReads == 0) { *out = res.release(); return; }
 
@@ -860,7 +880,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         runFinalize(ctx, idx, reads, p, res.get(), ctx->pool.as<RawMatch>(), nPool, nItems, maxMatchErr);
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
 
-        res->readLens = reads->lens;       // for the host-side MAPQ
+        res->readLens = reads->lens;       // for the host-side MAPQ (shared, not copied)
         HIP_CHECK(hipStreamSynchronize(st));
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
@@ -895,7 +915,7 @@ int dy_result_fetch(dy_result * r)
             d.mapped = o.mapped; d.best_count = o.bestCount; d.sub_count = o.subCount;
             d.paired = o.paired; d.reserved = 0; d.pair_prob = o.pairProb;
             d.mapq = !o.mapped ? 0 : o.paired ? (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(o.pairProb, 0.9999999)))
-                                              : mapqOf(o.errors, r->readLens[i], o.bestCount, o.subCount);
+                                              : mapqOf(o.errors, (*r->readLens)[i], o.bestCount, o.subCount);
             d.set_begin = (u32)r->matches.size();
             u32 nset = o.bestCount + o.subCount;
             for (u32 k = 0; k < nset; ++k)
@@ -924,7 +944,13 @@ const dy_read_result * dy_result_reads(const dy_result * r) { return (r && r->fe
 const dy_match * dy_result_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.data() : nullptr; }
 uint64_t dy_result_n_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.size() : 0; }
 const uint32_t * dy_result_cigars(const dy_result * r) { return (r && r->fetched) ? r->cigarOps.data() : nullptr; }
-void dy_result_free(dy_result * r) { if (r) { (void)hipSetDevice(r->ctx->device); delete r; } }
+void dy_result_free(dy_result * r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->ctx->device);
+    giveBuffer(r->ctx, r->out); giveBuffer(r->ctx, r->outSet); giveBuffer(r->ctx, r->cigars);
+    delete r;
+}
 
 int dy_map_get_stats(const dy_ctx * ctx, dy_map_stats * s)
 {
@@ -998,8 +1024,8 @@ int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_
         HIP_CHECK(hipSetDevice(ctx->device));
         std::unique_ptr<dy_reads> r(new dy_reads);
         r->ctx = ctx; r->n = n_reads; r->totalBases = n_bases;
-        r->lens.resize(n_reads);
-        if (n_reads) HIP_CHECK(hipMemcpyAsync(r->lens.data(), lens_dev, (size_t)n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
+        r->lens->resize(n_reads);
+        if (n_reads) HIP_CHECK(hipMemcpyAsync(r->lens->data(), lens_dev, (size_t)n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
         r->seqs.reserve(n_bases + 64); r->seqsRc.reserve(n_bases + 64);
         r->offs.reserve((size_t)(n_reads + 1) * 8);
         const u32 W = (n_bins + 63) / 64;
@@ -1015,7 +1041,7 @@ int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->planReads = nullptr;        // shLen was reused
         u64 sum = 0; u32 mx = 0, mn = 0xFFFFFFFFu;
-        for (u32 l : r->lens) { if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded."); sum += l; mx = std::max(mx, l); mn = std::min(mn, l); }
+        for (u32 l : *r->lens) { if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded."); sum += l; mx = std::max(mx, l); mn = std::min(mn, l); }
         if (sum != n_bases) throw DyError(DY_EINVAL, "dy_reads_from_device: lengths do not add up to n_bases");
         r->maxLen = mx; r->minLen = n_reads ? mn : 0;
         *out = r.release();
