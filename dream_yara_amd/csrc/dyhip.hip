@@ -134,7 +134,8 @@ struct dy_index
     std::vector<BinDesc> bins;
     std::vector<std::string> contigNames;
     std::vector<u64> contigLengths;
-    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable;
+    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable, isa, ftext;
+    bool hasIsa = false;
     bool hasFullSa = false, multiContig = false, sharded = false;
     std::vector<u64> ownedMask;     // bins whose FM structures are resident (all of them unless loaded sharded)
     DevBuf dOwnedMask;
@@ -147,6 +148,7 @@ struct dy_index
         v.saFullOffset = hasFullSa ? saFullOffset.as<u32>() : nullptr;
         v.saFullContig = (hasFullSa && multiContig) ? saFullContig.as<u16>() : nullptr;
         v.prefixTable = prefixQ ? prefixTable.as<uint2>() : nullptr; v.prefixQ = prefixQ;
+        v.isa = hasIsa ? isa.as<u32>() : nullptr; v.ftext = hasIsa ? ftext.as<u8>() : nullptr;
         v.nBins = (u32)bins.size();
         return v;
     }
@@ -809,6 +811,22 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
                 HIP_CHECK(hipStreamSynchronize(ctx->stream));
                 idx->prefixQ = q;
             }
+        }
+        // inverse SA + indexed text (DY_NO_ISA=1 keeps the pure LF walk, for comparison)
+        HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+        if (idx->hasFullSa && idx->prefixQ && !getenv("DY_NO_ISA") && totalRows * 4 + H.contigs.size() + 4096 < freeB / 4)
+        {
+            idx->isa.reserve(totalRows * 4 + 64);
+            idx->ftext.reserve(H.contigs.size() + 64);
+            HIP_CHECK(hipMemcpyAsync(idx->ftext.p, idx->contigs.p, H.contigs.size(), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_CHECK(hipMemsetAsync(idx->isa.p, 0, totalRows * 4, ctx->stream));
+            IndexView v = idx->view();
+            for (u32 b = 0; b < n_bins; ++b)
+                if (idx->bins[b].n)
+                    hipLaunchKernelGGL(k_build_isa_ftext, dim3((idx->bins[b].n + 255) / 256), dim3(256), 0, ctx->stream, v, b, idx->isa.as<u32>(), idx->ftext.as<u8>());
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            idx->hasIsa = true;
         }
         *out = idx.release();
     });

@@ -22,6 +22,8 @@ struct IndexView
     const u32 *     saFullOffset;   // expanded SA (one entry per BWT row) or nullptr: then the sparse SA is walked
     const u16 *     saFullContig;   // nullptr when every bin has a single contig
     const uint2 *   prefixTable;    // per bin 4^q (lo,hi) ranges of every q-mer, or nullptr
+    const u32 *     isa;            // inverse of the expanded SA: row of the suffix at (contig, offset in the reversed contig), or nullptr
+    const u8 *      ftext;          // the INDEXED text (Ns randomised), forward, laid out like `contigs`; position 0 of a contig is undefined
     u32             prefixQ;
     u32             nBins;
 };
@@ -180,6 +182,23 @@ __global__ void k_prefix_level(IndexView ix, u32 bin, const uint2 * __restrict__
     }
     else r = make_uint2(0u, 0u);
     child[i] = r;
+}
+
+// Device-only companions of the expanded SA, filled once at load time: the inverse SA and the indexed text itself (recovered
+// from the BWT: the symbol in front of the suffix at reversed offset x is forward base clen - x).  With them a seed whose
+// q-mer range is narrow is finished by comparing the rest of the seed with the text instead of walking LF (k_seed_search).
+__global__ void k_build_isa_ftext(IndexView ix, u32 bin, u32 * __restrict__ isa, u8 * __restrict__ ftext)
+{
+    const BinView b = makeBinView(ix, bin);
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= b.n || row < b.nContigs) return;
+    u32 contig, x;
+    fmLocate(b, row, contig, x);
+    const u64 lim = b.limits[contig];
+    const u32 clen = (u32)(b.limits[contig + 1] - lim);
+    if (x >= clen) return;
+    isa[ix.bins[bin].saFullOff + lim + x] = row;
+    if (x >= 1) ftext[ix.bins[bin].contigOff + lim + (clen - x)] = (u8)bwtSymbol(b, row);
 }
 
 __global__ void k_expand_sa(IndexView ix, u32 bin, u32 * __restrict__ outOffset, u16 * __restrict__ outContig)

@@ -208,6 +208,28 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
             for (u32 d = 0; d < ix.prefixQ; ++d) { const u32 c = readBase(seq, len, strand, off + d); ok &= c < 4; idx = idx * 4 + (c & 3); }
             if (ok) { const uint2 r = ix.prefixTable[ix.bins[bin].prefixOff + idx]; lo = r.x; hi = r.y; ok = lo < hi; }
             d0 = ix.prefixQ;
+            if (ok && ix.isa && hi - lo <= 4 && seedLen > d0)
+            {   // narrow range: every occurrence of the seed starts with one of these q-mer occurrences — compare the rest of the
+                // seed with the indexed text (1 locate + 1 compare + 1 inverse-SA gather instead of seedLen - q dependent LF steps)
+                const u32 rem = seedLen - d0;
+                const u8 * pat = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off + d0;
+                const u8 * ftext = ix.ftext + ix.bins[bin].contigOff;
+                const u32 * isa = ix.isa + ix.bins[bin].saFullOff;
+                u32 found = 0, first = 0xFFFFFFFFu;
+                for (u32 row = lo; row < hi; ++row)
+                {
+                    u32 contig, x;
+                    fmLocate(b, row, contig, x);
+                    const u64 lim = b.limits[contig];
+                    const u32 clen = (u32)(b.limits[contig + 1] - lim);
+                    if (x < rem) continue;                                       // the seed would start before the contig does
+                    if (countMismatches(ftext + lim + (clen - x), pat, (int)rem)) continue;
+                    ++found;
+                    first = min(first, isa[lim + x - rem]);
+                }
+                hits0[(size_t)item * slots + slot] = found ? make_uint2(first, first + found) : make_uint2(0u, 0u);
+                return;
+            }
         }
         for (u32 d = d0; d < seedLen && ok; ++d)
         {
