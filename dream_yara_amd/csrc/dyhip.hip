@@ -325,12 +325,19 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             HIP_CHECK(hipEventRecord(ctx->evFork, st));
             HIP_CHECK(hipStreamWaitEvent(ctx->side[0], ctx->evFork, 0));
             HIP_CHECK(hipStreamWaitEvent(ctx->side[1], ctx->evFork, 0));
-            hipLaunchKernelGGL(k_finalize_small, dim3(1024), dim3(256), 0, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
+            // thread-level DP kernels: 64-thread blocks, trace rows in LDS ((maxLen + 1) rows x 64 threads x 4 or 8 bytes)
+            const bool narrowBand = maxMatchErr <= 3;
+            const u32 traceRows = std::min<u32>(reads->maxLen, THREAD_DP_MAX_LEN) + 1;
+            const u32 dpThreads = (size_t)traceRows * 64 * (narrowBand ? 4 : 8) > 60 * 1024 ? 32 : 64;      // stay within 64 KB of LDS per block
+            const size_t traceLds = (size_t)traceRows * dpThreads * (narrowBand ? 4 : 8);
+            if (narrowBand) hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
+            else hipLaunchKernelGGL((k_finalize_small<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
             hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa);
             HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
             HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
             hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount);
-            hipLaunchKernelGGL(k_align_single, dim3(2048), dim3(256), 0, st, fa, ctx->dpList.as<u32>(), dpCount);
+            if (narrowBand) hipLaunchKernelGGL((k_align_single<3, u32>), dim3(8192), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
+            else hipLaunchKernelGGL((k_align_single<7, u64>), dim3(8192), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
         }
@@ -386,7 +393,14 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             u32 * peAlignCount = ctx->counters.as<u32>() + 9;
             hipLaunchKernelGGL(k_pe_route, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount,
                                ctx->alignList.as<u32>(), peAlignCount);
-            hipLaunchKernelGGL(k_pe_align_single, dim3(1024), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+            {
+                const bool narrowBand = maxMatchErr <= 3;
+                const u32 traceRows = std::min<u32>(reads->maxLen, THREAD_DP_MAX_LEN) + 1;
+                const u32 dpThreads = (size_t)traceRows * 64 * (narrowBand ? 4 : 8) > 60 * 1024 ? 32 : 64;
+                const size_t traceLds = (size_t)traceRows * dpThreads * (narrowBand ? 4 : 8);
+                if (narrowBand) hipLaunchKernelGGL((k_pe_align_single<3, u32>), dim3(4096), dim3(dpThreads), traceLds, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+                else hipLaunchKernelGGL((k_pe_align_single<7, u64>), dim3(4096), dim3(dpThreads), traceLds, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+            }
             hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
         }
         HIP_CHECK(hipGetLastError());

@@ -285,23 +285,34 @@ __device__ inline bool alignIsUngapped2(const u8 * __restrict__ ctg, const u8 * 
 // (loops fully unrolled over the 15 possible diagonals), the trace is one 64-bit word per row (4 bits per cell) in
 // private memory.  Same values, tie-breaks and traceback as alignMatchDevice; used by the one-match fast path.
 enum { THREAD_DP_MAX_LEN = 160, THREAD_DP_MAX_E = 7 };
+// EMAX bounds the error budget of every match the kernel will see (3: a 7-diagonal band, 28 trace bits per row; 7: 15
+// diagonals, 60 bits).  The trace lives in LDS, one TRow per (row, thread) at trace[row * traceStride]: the traceback is a
+// chain of ~readLen dependent loads, which in private (global) memory was most of the latency of these list kernels.
+template <int EMAX, typename TRow>
 __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const u8 * __restrict__ seq, u32 readLen, u32 strand, int e,
-                                       u32 * cigarOut, u32 cigarCap, int & clipBegin, int & clipEnd)
+                                       u32 * cigarOut, u32 cigarCap, int & clipBegin, int & clipEnd, TRow * __restrict__ trace, u32 traceStride)
 {
-    enum { BM = 2 * THREAD_DP_MAX_E + 1 };
+    enum { BM = 2 * EMAX + 1 };
+    static_assert(4 * BM <= 8 * sizeof(TRow), "trace row too narrow");
     const int m = (int)readLen, B = 2 * e + 1;
     const int NEG = -(1 << 28), MISMATCH = -1000, GEXT = -999, GOPEN = -1001;
-    u64 trace[THREAD_DP_MAX_LEN + 1];
     int pS[BM], pV[BM];
+    u32 cw[BM];          // contig base under cell (i, d): ctg[i + d - e - 1], 5 outside the window (matches nothing)
 #pragma unroll
-    for (int d = 0; d < BM; ++d) { const int j = d - e; pS[d] = (d < B && j >= 0 && j <= n) ? 0 : NEG; pV[d] = NEG; }
+    for (int d = 0; d < BM; ++d)
+    {
+        const int j = d - e;
+        pS[d] = (d < B && j >= 0 && j <= n) ? 0 : NEG; pV[d] = NEG;
+        const int idx = 1 + d - e - 1;
+        cw[d] = (idx >= 0 && idx < n) ? ctg[idx] : 5u;
+    }
     trace[0] = 0;
     for (int i = 1; i <= m; ++i)
     {
         const u32 rc = readBase(seq, readLen, strand, (u32)(i - 1));
         int cS[BM], cV[BM];
         int leftS = NEG, leftH = NEG;
-        u64 row = 0;
+        TRow row = 0;
 #pragma unroll
         for (int d = 0; d < BM; ++d)
         {
@@ -322,7 +333,7 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
                 u32 tb = 0;
                 if (j >= 1)
                 {
-                    const u32 cc = ctg[j - 1];
+                    const u32 cc = cw[d];
                     s = pS[d] + ((cc == rc && cc < 4) ? 0 : MISMATCH); tb = 1;
                 }
                 if (v > s) { s = v; tb = 3; }
@@ -330,11 +341,13 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
                 tr |= tb;
             }
             cS[d] = s; cV[d] = v; leftS = s; leftH = h;
-            row |= (u64)tr << (4 * d);
+            row |= (TRow)tr << (4 * d);
         }
-        trace[i] = row;
+        trace[(size_t)i * traceStride] = row;
+        const int nextIdx = i + BM - 1 - e;
+        const u32 incoming = (nextIdx >= 0 && nextIdx < n) ? ctg[nextIdx] : 5u;
 #pragma unroll
-        for (int d = 0; d < BM; ++d) { pS[d] = cS[d]; pV[d] = cV[d]; }
+        for (int d = 0; d < BM; ++d) { pS[d] = cS[d]; pV[d] = cV[d]; cw[d] = d + 1 < BM ? cw[d + 1 < BM ? d + 1 : d] : incoming; }
     }
     int bj = -1, bs = NEG;
 #pragma unroll
@@ -350,7 +363,7 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
         int ti = i, tj = j, ts = 0;
         while (ti > 0)
         {
-            const u32 tr = (u32)(trace[ti] >> (4 * (tj - ti + e))) & 15;
+            const u32 tr = (u32)(trace[(size_t)ti * traceStride] >> (4 * (tj - ti + e))) & 15;
             int op;
             if (ts == 0)
             {
@@ -372,7 +385,7 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
         u32 slot = runs; lastOp = -1; u32 run = 0;
         while (i > 0)
         {
-            const u32 tr = (u32)(trace[i] >> (4 * (j - i + e))) & 15;
+            const u32 tr = (u32)(trace[(size_t)i * traceStride] >> (4 * (j - i + e))) & 15;
             int op;
             if (state == 0)
             {
@@ -839,8 +852,11 @@ __global__ __launch_bounds__(256) void k_align_check(FinalizeArgs A, const u32 *
 }
 
 // alignMatches for reads whose only match needs the DP: CIGAR + shrink (reference src/mapper_aligner.h:204-236)
-__global__ __launch_bounds__(256) void k_align_single(FinalizeArgs A, const u32 * __restrict__ alignList, const u32 * __restrict__ alignCount)
+template <int EMAX, typename TRow>
+__global__ __launch_bounds__(64) void k_align_single(FinalizeArgs A, const u32 * __restrict__ alignList, const u32 * __restrict__ alignCount)
 {
+    extern __shared__ u64 dpTraceLds[];
+    TRow * trace = (TRow *)dpTraceLds + threadIdx.x;
     const u32 nList = *alignCount;
     for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
     {
@@ -852,8 +868,8 @@ __global__ __launch_bounds__(256) void k_align_single(FinalizeArgs A, const u32 
         const BinDesc & bd = A.bins[a.bin];
         const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
         int cb, ce;
-        const u32 nc = alignMatchThread(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
-                                        A.cigars + ro.cigarBegin, A.cigarStride, cb, ce);
+        const u32 nc = alignMatchThread<EMAX, TRow>(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
+                                                    A.cigars + ro.cigarBegin, A.cigarStride, cb, ce, trace, blockDim.x);
         ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
         a.begin += (u32)cb; a.len = (u16)ce;
         writeSingleMatch(A, read, ro, a);
@@ -875,8 +891,11 @@ __device__ __forceinline__ void insertionSortIdx(u32 * idx, u32 cnt, TLess less)
     }
 }
 
-__global__ __launch_bounds__(256) void k_finalize_small(FinalizeArgs A, const u32 * __restrict__ smallList, const u32 * __restrict__ smallCount)
+template <int EMAX, typename TRow>
+__global__ __launch_bounds__(64) void k_finalize_small(FinalizeArgs A, const u32 * __restrict__ smallList, const u32 * __restrict__ smallCount)
 {
+    extern __shared__ u64 dpTraceLds[];
+    TRow * trace = (TRow *)dpTraceLds + threadIdx.x;
     const u32 nList = *smallCount;
     for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
     {
@@ -929,8 +948,8 @@ __global__ __launch_bounds__(256) void k_finalize_small(FinalizeArgs A, const u3
                         const BinDesc & bd = A.bins[a.bin];
                         const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
                         int cb, ce;
-                        const u32 nc = alignMatchThread(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors,
-                                                        winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
+                        const u32 nc = alignMatchThread<EMAX, TRow>(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors,
+                                                                    winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, trace, blockDim.x);
                         if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
                         a.begin += (u32)cb; a.len = (u16)ce;
                     }

@@ -698,9 +698,12 @@ __global__ __launch_bounds__(1024) void k_pe_route(FinalizeArgs A, PeView V, con
 }
 
 // Single-entry reads whose primary needs the alignment DP (thread-level DP, all lanes busy)
-__global__ __launch_bounds__(256) void k_pe_align_single(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, const u32 * __restrict__ alignList,
-                                                         const u32 * __restrict__ alignCount)
+template <int EMAX, typename TRow>
+__global__ __launch_bounds__(64) void k_pe_align_single(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, const u32 * __restrict__ alignList,
+                                                        const u32 * __restrict__ alignCount)
 {
+    extern __shared__ u64 dpTraceLds[];
+    TRow * trace = (TRow *)dpTraceLds + threadIdx.x;
     const u32 nList = *alignCount;
     for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
     {
@@ -715,8 +718,8 @@ __global__ __launch_bounds__(256) void k_pe_align_single(FinalizeArgs A, PeView 
         const BinDesc & bd = A.bins[bin];
         const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
         int cb, ce;
-        const u32 nc = alignMatchThread(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
-                                        A.cigars + ro.cigarBegin, A.cigarStride, cb, ce);
+        const u32 nc = alignMatchThread<EMAX, TRow>(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors,
+                                                    A.cigars + ro.cigarBegin, A.cigarStride, cb, ce, trace, blockDim.x);
         ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
         a.begin += (u32)cb; a.len = (u16)ce;
         ro.paired = it.paired ? 1 : 0; ro.pairProb = it.paired ? it.prob : 0.0;
