@@ -841,6 +841,17 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             idx->hasIsa = true;
+            // unique q-mers: position instead of row
+            {
+                IndexView v2 = idx->view();
+                const u32 nEntries = 1u << (2 * idx->prefixQ);
+                for (u32 b = 0; b < n_bins; ++b)
+                    if (idx->bins[b].n)
+                        hipLaunchKernelGGL(k_prefix_direct, dim3((nEntries + 255) / 256), dim3(256), 0, ctx->stream, v2, b,
+                                           idx->prefixTable.as<uint2>() + idx->bins[b].prefixOff, nEntries);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            }
         }
         *out = idx.release();
     });

@@ -201,6 +201,26 @@ __global__ void k_build_isa_ftext(IndexView ix, u32 bin, u32 * __restrict__ isa,
     if (x >= 1) ftext[ix.bins[bin].contigOff + lim + (clen - x)] = (u8)bwtSymbol(b, row);
 }
 
+// "Direct" encodings (only used when the inverse SA / indexed text exist).  Rows stay below 0xFFFE0000 (bins above ~4.29 Gbp
+// are refused at load), so a second word at or above a tag cannot be a range end:
+//   q-mer table entry (x, DIRECT_QMER | contig): the q-mer occurs once; x = offset of its suffix in the reversed contig
+//   seed hit          (x, DIRECT_HIT  | contig): one occurrence of the whole seed, located; x as for fmLocate
+enum : u32 { DIRECT_QMER = 0xFFFE0000u, DIRECT_HIT = 0xFFFF0000u };
+__device__ __forceinline__ u32 hitCount(uint2 r) { return r.y >= DIRECT_HIT ? 1u : r.y - r.x; }
+
+// after the expanded SA exists: unique q-mers carry their position instead of their row (saves the locate on the mapping path)
+__global__ void k_prefix_direct(IndexView ix, u32 bin, uint2 * __restrict__ table, u32 nEntries)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nEntries) return;
+    const uint2 r = table[i];
+    if (r.y - r.x != 1 || r.y >= DIRECT_QMER) return;
+    const BinView b = makeBinView(ix, bin);
+    u32 contig, x;
+    fmLocate(b, r.x, contig, x);
+    table[i] = make_uint2(x, DIRECT_QMER | contig);
+}
+
 __global__ void k_expand_sa(IndexView ix, u32 bin, u32 * __restrict__ outOffset, u16 * __restrict__ outContig)
 {
     BinView b = makeBinView(ix, bin);

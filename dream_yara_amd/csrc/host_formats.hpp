@@ -115,6 +115,7 @@ inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = t
             throw IoError("Error while opening reference index file.");
         d.n = loadLE<u32>(len.data());
         if (d.n != sum + nContigs) throw IoError("sa.len does not match txt.size in " + prefix);
+        if (d.n >= 0xFFFE0000u) throw IoError("bins above 4.29 Gbp are not supported (" + prefix + ")");      // rows must stay below the DIRECT_* tags
         for (int c = 0; c < 4; ++c) d.pst[c] = loadLE<u32>(pst.data() + 4 * c);
         d.drs = drs.data()[0];
         if (drp.size() != nContigs * 4) throw IoError("unexpected lf.drp size in " + prefix);

@@ -206,28 +206,50 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
         {   // first q characters through the q-mer table
             u32 idx = 0;
             for (u32 d = 0; d < ix.prefixQ; ++d) { const u32 c = readBase(seq, len, strand, off + d); ok &= c < 4; idx = idx * 4 + (c & 3); }
-            if (ok) { const uint2 r = ix.prefixTable[ix.bins[bin].prefixOff + idx]; lo = r.x; hi = r.y; ok = lo < hi; }
             d0 = ix.prefixQ;
-            if (ok && ix.isa && hi - lo <= 4 && seedLen > d0)
-            {   // narrow range: every occurrence of the seed starts with one of these q-mer occurrences — compare the rest of the
-                // seed with the indexed text (1 locate + 1 compare + 1 inverse-SA gather instead of seedLen - q dependent LF steps)
+            if (ok)
+            {
+                const uint2 r = ix.prefixTable[ix.bins[bin].prefixOff + idx];
+                if (r.y >= DIRECT_QMER)
+                {   // the q-mer occurs once and the table holds its position: compare the rest of the seed with the indexed text
+                    const u32 rem = seedLen - d0, contig = r.y & 0xFFFFu, x = r.x;
+                    const u64 lim = b.limits[contig];
+                    const u32 clen = (u32)(b.limits[contig + 1] - lim);
+                    uint2 hit = make_uint2(0u, 0u);
+                    if (x >= rem)                                                // else the seed would start before the contig does
+                    {
+                        const u8 * pat = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off + d0;
+                        if (!countMismatches(ix.ftext + ix.bins[bin].contigOff + lim + (clen - x), pat, (int)rem)) hit = make_uint2(x - rem, DIRECT_HIT | contig);
+                    }
+                    hits0[(size_t)item * slots + slot] = hit;
+                    return;
+                }
+                lo = r.x; hi = r.y; ok = lo < hi;
+            }
+            if (ok && ix.isa && hi - lo <= 4)
+            {   // narrow range: every occurrence of the seed starts with one of these q-mer occurrences (1 locate + 1 compare each,
+                // instead of seedLen - q dependent LF steps); several survivors go back to rows through the inverse SA
                 const u32 rem = seedLen - d0;
                 const u8 * pat = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off + d0;
                 const u8 * ftext = ix.ftext + ix.bins[bin].contigOff;
                 const u32 * isa = ix.isa + ix.bins[bin].saFullOff;
-                u32 found = 0, first = 0xFFFFFFFFu;
+                u32 found = 0, first = 0xFFFFFFFFu, oneX = 0, oneContig = 0;
                 for (u32 row = lo; row < hi; ++row)
                 {
                     u32 contig, x;
                     fmLocate(b, row, contig, x);
                     const u64 lim = b.limits[contig];
                     const u32 clen = (u32)(b.limits[contig + 1] - lim);
-                    if (x < rem) continue;                                       // the seed would start before the contig does
+                    if (x < rem) continue;
                     if (countMismatches(ftext + lim + (clen - x), pat, (int)rem)) continue;
                     ++found;
-                    first = min(first, isa[lim + x - rem]);
+                    oneX = x - rem; oneContig = contig;
+                    if (found > 1 || row + 1 < hi) first = min(first, isa[lim + x - rem]);
                 }
-                hits0[(size_t)item * slots + slot] = found ? make_uint2(first, first + found) : make_uint2(0u, 0u);
+                uint2 hit = make_uint2(0u, 0u);
+                if (found == 1) hit = make_uint2(oneX, DIRECT_HIT | oneContig);
+                else if (found > 1) hit = make_uint2(first, first + found);
+                hits0[(size_t)item * slots + slot] = hit;
                 return;
             }
         }
@@ -477,7 +499,7 @@ __device__ void fmBacktrack(const BinView & b, const u8 * __restrict__ seq, u32 
 __device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S0, const MapParams & prm)
 {
     u64 total = 0;
-    for (u32 s = 0; s < 2 * S0; ++s) total += h0[s].y - h0[s].x;
+    for (u32 s = 0; s < 2 * S0; ++s) total += hitCount(h0[s]);
     if (total > prm.hitsThreshold) return (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
     return 0;
 }
@@ -510,19 +532,21 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
     bool active = valid && seedErrors == 0 && len >= cnt0;
     const u32 seedLen = active ? len / cnt0 : 0;
     u32 done[2] = {0, 0};   // bitmask of seeds already taken per strand (cnt0 <= 32)
-    u32 rank = 0, strand = 0, row = 0, rowEnd = 0, needleBegin = 0;
+    u32 rank = 0, strand = 0, row = 0, rowEnd = 0, needleBegin = 0, directX = 0, directContig = 0;
+    bool direct = false;
     auto pickSeed = [&]() {
         u32 best = 0xFFFFFFFFu, bestId = 0;
         for (u32 k = 0; k < cnt0; ++k)
         {
             if (done[strand] >> k & 1) continue;
-            const uint2 r = h0[strand * S0 + k];
-            const u32 c = r.y - r.x;
+            const u32 c = hitCount(h0[strand * S0 + k]);
             if (c < best) { best = c; bestId = k; }
         }
         done[strand] |= 1u << bestId;
         const uint2 r = h0[strand * S0 + bestId];
-        row = r.x; rowEnd = r.y; needleBegin = (cnt0 - 1 - bestId) * seedLen;
+        needleBegin = (cnt0 - 1 - bestId) * seedLen;
+        if (r.y >= DIRECT_HIT) { direct = true; directX = r.x; directContig = r.y & 0xFFFFu; row = 0; rowEnd = 1; }     // located by K2
+        else { direct = false; row = r.x; rowEnd = r.y; }
     };
     if (active) pickSeed();
     for (;;)
@@ -543,7 +567,7 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
         if (have && !(sink.debugFlags & 2))
         {   // _extendHitImpl for one SA row (reference src/mapper_extender.h:263-285)
             u32 contig, x;
-            fmLocate(b, row, contig, x);
+            if (direct) { contig = directContig; x = directX; } else fmLocate(b, row, contig, x);
             ++row;
             const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
             if (clen - x >= seedLen && !(sink.debugFlags & 1))
