@@ -638,6 +638,74 @@ def test_update_filter_equals_fresh_build(product_build, dy, ctx, ob, tmp_path, 
     assert open(mine, "rb").read() == open(want, "rb").read()
 
 
+@pytest.mark.parametrize("use_filter", [True, False])
+def test_multi_contig_bins_match_oracle(dy, ctx, ob, tmp_path, use_filter):
+    """Bins with several contigs (incl. contigs shorter than a read, a repeat shared between contigs and Ns): exercises the
+    contig ids of the expanded SA, the inverse SA / indexed text and the position-carrying hits.  Unpinned by reference
+    fixtures (every gold bin has one contig); device == oracle."""
+    rng = np.random.default_rng(808)
+    n_bins = 4
+    all_codes, bin_offs = [], []
+    contigs_of = []
+    for b in range(n_bins):
+        lens = [20000, 60, 7000, 150, 12000][: 3 + b % 3]
+        cs = [rng.integers(0, 4, L, dtype=np.uint8) for L in lens]
+        cs[0][500:900] = cs[2][100:500]                       # a repeat across two contigs of the bin
+        cs[0][3000] = 4; cs[2][50:53] = 4
+        contigs_of.append(cs)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, cs in enumerate(contigs_of):
+        offs = np.zeros(len(cs) + 1, np.uint64); offs[1:] = np.cumsum([c.size for c in cs])
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), np.concatenate(cs), offs)
+    fpath = None
+    if use_filter:
+        fpath = str(tmp_path / "f.filter")
+        whole = [np.concatenate(cs) for cs in contigs_of]
+        goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in whole])
+        ob.build_filter(fpath, n_bins, 3, 14, 1 << 22, np.concatenate(whole), goffs)
+    reads = []
+    for i in range(2500):
+        cs = contigs_of[int(rng.integers(0, n_bins))]
+        c = cs[int(rng.integers(0, len(cs)))]
+        L = 100
+        if c.size < L + 4:
+            r = np.concatenate([c, rng.integers(0, 4, L - c.size, dtype=np.uint8)])[:L]      # hangs over a short contig
+        else:
+            s = int(rng.integers(0, c.size - L - 2)); r = c[s:s + L + 2].copy()
+            for _ in range(int(rng.integers(0, 4))):
+                q = int(rng.integers(0, L)); kind = rng.random()
+                if kind < 0.75: r[q] = (r[q] + 1) & 3
+                elif kind < 0.9: r = np.concatenate([r[:q], r[q + 1:]])
+                else: r = np.concatenate([r[:q], rng.integers(0, 4, 1, dtype=np.uint8), r[q:]])
+            r = r[:L]
+            if r.size < L: r = np.concatenate([r, rng.integers(0, 4, L - r.size, dtype=np.uint8)])
+        if i % 2: r = np.where(r[::-1] < 4, 3 - r[::-1], 4).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    er = np.float32(0.03)
+    idx = dy.Index(ctx, idx_dir, n_bins); rd = dy.Reads(ctx, codes, offs)
+    params = dy.default_params(error_rate=er, strata_rate=np.float32(0.02))
+    ibf = None
+    if fpath:
+        ibf = dy.Ibf.load(ctx, fpath); ibf.query(rd, dy.threshold(er, 14, 100), want_masks=False)
+    else:
+        params.use_filter = 0
+    res = dy.map_reads(ctx, idx, rd, params)
+    dev = (res.reads(), res.matches(), res.cigars()); stats = ctx.stats()
+    names = idx.contig_names()
+    res.close(); rd.close(); idx.close()
+    if ibf: ibf.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath) if fpath else None
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er, np.float32(0.02))
+    assert len(names) == sum(len(cs) for cs in contigs_of)
+    assert stats["items"] == ostats["items"] and stats["raw_matches"] == ostats["raw_matches"]
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
+    assert int(dev[0]["mapped"].sum()) > 1500          # reads sampled from the 60- and 150-base contigs cannot map
+    assert len(set(dev[0]["primary"]["contig"][dev[0]["mapped"] == 1].tolist())) > 8         # many different contigs are hit
+    oidx.close()
+    if oibf: oibf.close()
+
+
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
 @pytest.mark.parametrize("strata", [0.0, 0.02])
 def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata):
