@@ -179,6 +179,23 @@ def test_map_matches_oracle_on_gold_data(dy, ctx, ob, small_filter, strata):
     oidx.close(); oibf.close()
 
 
+@pytest.mark.parametrize("env", [{"DY_SPARSE_SA": "1"}, {"DY_PREFIX_Q": "0"}, {"DY_NO_ISA": "1"}, {"DY_PREFIX_Q": "6"}])
+def test_map_without_the_device_only_tables(dy, ctx, ob, small_filter, monkeypatch, env):
+    """The HBM-sized tables (expanded SA, q-mer ranges, inverse SA + indexed text) only accelerate: with each of them switched
+    off at load time the results stay identical to the oracle (sparse-SA walk, plain LF search, row-range hits)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _, codes, offs = read_fasta_codes(READS_FA)
+    codes, offs = codes[: int(offs[2500])], offs[:2501]
+    er = np.float32(3 / 100.0)
+    dev, stats = device_map(dy, ctx, GOLD_INDEX, 64, small_filter, codes, offs, er, np.float32(0.05))
+    oidx = ob.OracleIndex(GOLD_INDEX, 64); oibf = ob.OracleIbf(small_filter)
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er, np.float32(0.05))
+    assert stats["items"] == ostats["items"] and stats["raw_matches"] == ostats["raw_matches"]
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
+    oidx.close(); oibf.close()
+
+
 @pytest.mark.parametrize("gold,extra", [("t1", []), ("tag.t1", ["-sm", "tag", "-s", "10"]), ("rec.t1", ["-sm", "record", "-s", "10"])])
 def test_cli_reproduces_gold_sam(product_build, dy, small_filter, tmp_path, gold, extra):
     out = str(tmp_path / "out.sam")
