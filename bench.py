@@ -30,6 +30,12 @@ WORKLOADS = {
     # name: bins, genome length per bin, IBF GiB, k, hashes, reads per GPU, read length, error %
     "config2": dict(bins=64, glen=4_000_000, ibf_gib=1, k=18, h=3, reads=1_000_000, L=100, e=3,
                     desc="64 bins x 4 Mbp, 1 GiB IBF (k=18, 3 hashes), 1M synthetic 100 bp SE reads, e=3"),
+    # BASELINE.json configs[2] geometry on ONE GPU (256 bins, 16 GiB filter, W = 4): not the default; `--workload config3`
+    "config3": dict(bins=256, glen=4_000_000, ibf_gib=16, k=18, h=3, reads=1_000_000, L=100, e=3,
+                    desc="256 bins x 4 Mbp, 16 GiB IBF (k=18, 3 hashes), 1M synthetic 100 bp SE reads per step, e=3"),
+    # BASELINE.json configs[4] geometry on ONE GPU (1024 bins, 64 GiB filter resident, W = 16, 150 bp, e = 5): `--workload config5`
+    "config5": dict(bins=1024, glen=4_000_000, ibf_gib=64, k=18, h=3, reads=1_000_000, L=150, e=5,
+                    desc="1024 bins x 4 Mbp, 64 GiB IBF (k=18, 3 hashes), 1M synthetic 150 bp SE reads per step, e=5"),
     # small variant for smoke runs / CI (NOT the reported configuration)
     "tiny": dict(bins=64, glen=100_000, ibf_gib=0, k=18, h=3, reads=20_000, L=100, e=3,
                  desc="64 bins x 100 kbp, 32 MiB IBF, 20k reads (smoke only)"),
@@ -203,9 +209,11 @@ def main():
                        "mapped_fraction": mapped_fraction, "primary_in_true_bin": ok_bin,
                        "items_per_read": (stats["items"] if sm is None else sm.last["items"] / world) / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
                        "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
-            "roofline": {"kernel": "k_ibf_query", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"kernel": "k_ibf_query" if W == 1 else "k_ibf_query_wide", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "note": "algorithmic bytes %d B/read x %d reads per launch; every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87%% busy at the same time (profiles/r01f_pmc_sq_config2.json)" % (bytes_per_read, wl["reads"])},
+                         "note": ("algorithmic bytes %d B/read x %d reads per launch; " % (bytes_per_read, wl["reads"])) +
+                                 ("every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87% busy at the same time (profiles/r01f_pmc_sq_config2.json)"
+                                  if W == 1 else "W = %d words per hash position are fetched by adjacent lanes (k_ibf_query_wide); bound by vector-ALU issue, see DESIGN.md" % W)},
         }
         if args.cpu_sample > 0 and world == 1:
             fpath = os.path.join(work_dir, "bench.filter")
