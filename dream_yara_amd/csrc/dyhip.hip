@@ -725,19 +725,20 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 while ((1u << gShift) < W && gShift < 4) ++gShift;
                 const u32 G = 1u << gShift;
                 const u32 nK = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
-                const u32 cacheKmers = std::min<u32>(nK, (19 * 1024 - 1024) / (G * 8));
-                const size_t perWave = (128 + (size_t)cacheKmers * G) * 8;
+                const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
+                const u32 cacheKmers = std::min<u32>(nK, (u32)((19 * 1024 - hashSlots * 8) / (G * 8)));
+                const size_t perWave = (hashSlots + (size_t)cacheKmers * G) * 8;
                 const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
                 if (nK <= 127)
                     hipLaunchKernelGGL(k_ibf_query_wide<7>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
-                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers);
+                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots);
                 else if (nK <= 255)
                     hipLaunchKernelGGL(k_ibf_query_wide<8>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
-                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers);
+                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots);
                 else
                     hipLaunchKernelGGL(k_ibf_query_wide<14>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
-                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers);
+                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots);
             }
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));

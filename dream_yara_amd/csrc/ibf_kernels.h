@@ -272,9 +272,35 @@ __device__ __forceinline__ void planesAddBit(u64 (&planes)[NP], u64 m)
 #pragma unroll
     for (int p = 0; p < NP; ++p) { const u64 t = planes[p] & carry; planes[p] ^= carry; carry = t; }
 }
-// sum of the per-lane counters over the lanes that differ in bits >= log2(G): every lane ends with its word's total
+// planes += m0 + ... + m7 (eight one-bit numbers per bin): carry-save tree to a 4-bit number, then one ripple add
 template <int NP>
-__device__ __forceinline__ void planesReduceSlots(u64 (&planes)[NP], u32 G)
+__device__ __forceinline__ void planesAdd8(u64 (&planes)[NP], const u64 (&m)[8])
+{
+    auto fa = [](u64 a, u64 b, u64 c, u64 & sum, u64 & carry) { const u64 x = a ^ b; sum = x ^ c; carry = (a & b) | (x & c); };
+    u64 s0, c0, s1, c1, s2, c2, ones, c3, t0, f0, twos, f1;
+    fa(m[0], m[1], m[2], s0, c0);
+    fa(m[3], m[4], m[5], s1, c1);
+    s2 = m[6] ^ m[7]; c2 = m[6] & m[7];
+    fa(s0, s1, s2, ones, c3);
+    fa(c0, c1, c2, t0, f0);
+    twos = t0 ^ c3; f1 = t0 & c3;
+    const u64 fours = f0 ^ f1, eights = f0 & f1;
+    const u64 add[4] = {ones, twos, fours, eights};
+    u64 carry = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+    {
+        const u64 v = p < 4 ? add[p] : 0;
+        const u64 x = planes[p] ^ v;
+        const u64 sum = x ^ carry;
+        carry = (planes[p] & v) | (carry & x);
+        planes[p] = sum;
+    }
+}
+// sum of the per-lane counters over the lanes that differ in bits >= log2(G): every lane ends with its word's total.
+// `width` = planes that can be non-zero in a single lane's counter; every butterfly step adds one.
+template <int NP>
+__device__ __forceinline__ void planesReduceSlots(u64 (&planes)[NP], u32 G, u32 width = NP)
 {
     for (u32 d = G; d < 64; d <<= 1)
     {
@@ -282,23 +308,26 @@ __device__ __forceinline__ void planesReduceSlots(u64 (&planes)[NP], u32 G)
 #pragma unroll
         for (int p = 0; p < NP; ++p)
         {
-            const u64 o = shflXor64(planes[p], (int)d);
-            const u64 x = planes[p] ^ o;
-            const u64 sum = x ^ carry;
-            carry = (planes[p] & o) | (carry & x);
-            planes[p] = sum;
+            if ((u32)p <= width)            // uniform: planes above the current width are zero on both sides
+            {
+                const u64 o = shflXor64(planes[p], (int)d);
+                const u64 x = planes[p] ^ o;
+                const u64 sum = x ^ carry;
+                carry = (planes[p] & o) | (carry & x);
+                planes[p] = sum;
+            }
         }
+        if (width < NP) ++width;
     }
 }
 
 template <int NP>
 __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__ words, IbfGeom g,
                                                         const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
-                                                        u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 cacheKmers)
+                                                        u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 cacheKmers, u32 hashSlots)
 {
     extern __shared__ u64 ldsWide[];
     constexpr u32 UA = 8, UB = 4;   // sub-passes whose gathers are in flight together (phase A / phase B)
-    constexpr u32 CH = 128;         // k-mers hashed per outer iteration (two ballots' worth)
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
     if (read >= nReads) return;
@@ -318,8 +347,13 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
     const u32 nKmers = len - k + 1;
     const u64 kMask = (1ull << k) - 1;
     const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
-    u64 * myHash = ldsWide + (size_t)wave * (CH + (size_t)cacheKmers * G);       // hashes of the current CH k-mers
-    u64 * myW0 = myHash + CH;                                                     // hash-0 words of the first cacheKmers k-mers
+    // LDS per wave: the k-mer hashes of one strand (all of them when hashSlots >= nKmers, else a window of hashSlots = 128) and
+    // the hash-0 words of the first cacheKmers k-mers
+    u64 * myHash = ldsWide + (size_t)wave * (hashSlots + (size_t)cacheKmers * G);
+    u64 * myW0 = myHash + hashSlots;
+    const bool hashAll = hashSlots >= nKmers;
+    const u32 CH = hashAll ? ((nKmers + 63) & ~63u) : hashSlots;        // k-mers per outer iteration
+    u32 perLaneBits = 1; while ((1u << perLaneBits) <= (nKmers + slots - 1) / slots) ++perLaneBits;   // bits of a lane's own counter
 
     for (u32 w0 = 0; w0 < g.W; w0 += G)
     {
@@ -338,8 +372,8 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
             for (u32 base = 0; base < nKmers; base += CH)
             {
                 __builtin_amdgcn_wave_barrier();
-                myHash[lane] = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
-                if (base + 64 < nKmers) myHash[64 + lane] = laneKmerHash(seq, len, strand, base + 64, lane, k, kMask, firstIsN);
+                for (u32 h0 = 0; h0 < CH && base + h0 < nKmers; h0 += 64)
+                    myHash[h0 + lane] = laneKmerHash(seq, len, strand, base + h0, lane, k, kMask, firstIsN);
                 __builtin_amdgcn_wave_barrier();
                 const u32 inChunk = min(CH, nKmers - base);
                 for (u32 s0 = 0; s0 * slots < inChunk; s0 += UA)
@@ -350,34 +384,39 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
                     {
                         const u32 kl = (s0 + u) * slots + slot;
                         const bool valid = kl < inChunk && wOk;
-                        m[u] = valid ? words[ibfWordIndex(g, myHash[kl & (CH - 1)], 0) + w] : 0;
+                        m[u] = valid ? words[ibfWordIndex(g, myHash[kl < CH ? kl : 0], 0) + w] : 0;
                     }
 #pragma unroll
                     for (u32 u = 0; u < UA; ++u)
                     {
                         const u32 kl = (s0 + u) * slots + slot;
                         if (kl < inChunk && base + kl < cacheKmers) myW0[(size_t)(base + kl) * G + wl] = m[u];
-                        planesAddBit(planes, m[u]);
                     }
+                    planesAdd8(planes, m);
                 }
             }
-            planesReduceSlots(planes, G);
+            planesReduceSlots(planes, G, perLaneBits);
             const u64 cand = planesGe(planes, (int)threshold) & binMask;
             const u64 candLanes = ballot64(cand != 0);
             if (candLanes == 0) continue;
+            // one candidate bin in the whole group (the usual case at high thresholds): its exact count is a popcount of ballots
+            const bool single = (u32)__popcll(candLanes) == slots && ballot64((cand & (cand - 1)) != 0) == 0;
             // few candidate words: fetch the remaining hash functions together; many (low thresholds): one after the other, lazily
             const bool eager = __popcll(candLanes) <= (int)(2 * slots);
             // ---- phase B
 #pragma unroll
             for (int p = 0; p < NP; ++p) planes[p] = 0;
-            u32 nextCheck = threshold + threshold / 4;
-            bool done = false;
+            u32 nextCheck = threshold + threshold / 4, exactOne = 0;
+            bool done = false, acceptOne = false;
             for (u32 base = 0; base < nKmers && !done; base += CH)
             {
-                __builtin_amdgcn_wave_barrier();
-                myHash[lane] = laneKmerHash(seq, len, strand, base, lane, k, kMask, firstIsN);
-                if (base + 64 < nKmers) myHash[64 + lane] = laneKmerHash(seq, len, strand, base + 64, lane, k, kMask, firstIsN);
-                __builtin_amdgcn_wave_barrier();
+                if (!hashAll)
+                {
+                    __builtin_amdgcn_wave_barrier();
+                    for (u32 h0 = 0; h0 < CH && base + h0 < nKmers; h0 += 64)
+                        myHash[h0 + lane] = laneKmerHash(seq, len, strand, base + h0, lane, k, kMask, firstIsN);
+                    __builtin_amdgcn_wave_barrier();
+                }
                 const u32 inChunk = min(CH, nKmers - base);
                 for (u32 s0 = 0; s0 * slots < inChunk; s0 += UB)
                 {
@@ -388,7 +427,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
                         const u32 kl = (s0 + u) * slots + slot;
                         const u32 kk = base + kl;
                         const bool valid = kl < inChunk && cand != 0;
-                        hk[u] = myHash[kl & (CH - 1)];
+                        hk[u] = myHash[kl < CH ? kl : 0];
                         c[u] = 0;
                         if (valid) c[u] = (kk < cacheKmers ? myW0[(size_t)kk * G + wl] : words[ibfWordIndex(g, hk[u], 0) + w]) & cand;
                     }
@@ -413,9 +452,18 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
 #pragma unroll
                             for (u32 u = 0; u < UB; ++u) c[u] &= v[u];
                         }
-#pragma unroll
-                    for (u32 u = 0; u < UB; ++u) planesAddBit(planes, c[u]);
                     const u32 processed = min(nKmers, base + min(CH, (s0 + UB) * slots));
+                    if (single)
+                    {
+#pragma unroll
+                        for (u32 u = 0; u < UB; ++u) exactOne += (u32)__popcll(ballot64(c[u] != 0));
+                        if (exactOne >= threshold) { acceptOne = true; done = true; break; }
+                        if (exactOne + (nKmers - processed) < threshold) { done = true; break; }
+                        continue;
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < UB; ++u)
+                        if (ballot64(c[u] != 0)) planesAddBit(planes, c[u]);
                     if (processed >= nextCheck && processed < nKmers)
                     {   // every candidate decided?  exact so far >= threshold, or out of reach even if all remaining k-mers hit
                         u64 e[NP];
@@ -428,8 +476,12 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
                     }
                 }
             }
-            planesReduceSlots(planes, G);
-            selW |= planesGe(planes, (int)threshold) & cand;
+            if (single) { if (acceptOne) selW |= cand; }
+            else
+            {
+                planesReduceSlots(planes, G);
+                selW |= planesGe(planes, (int)threshold) & cand;
+            }
         }
         if (slot == 0 && wOk) out[w] = selW;
     }
