@@ -726,7 +726,9 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 const u32 G = 1u << gShift;
                 const u32 nK = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
                 const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
-                const u32 cacheKmers = std::min<u32>(nK, (u32)((19 * 1024 - hashSlots * 8) / (G * 8)));
+                // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
+                const u32 ldsBudget = getenv("DY_IBF_LDS_KB") ? (u32)atoi(getenv("DY_IBF_LDS_KB")) * 1024 : 12 * 1024;
+                const u32 cacheKmers = ldsBudget > hashSlots * 8 ? std::min<u32>(nK, (u32)((ldsBudget - hashSlots * 8) / (G * 8))) : 0;
                 const size_t perWave = (hashSlots + (size_t)cacheKmers * G) * 8;
                 const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
