@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=1000000, help="reads in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--paired", action="store_true", help="paired-end batch: reads/2 pairs of 2 x L bp, insert N(400, 40) (BASELINE configs[3]); not the default metric")
     ap.add_argument("--shard", default="reads", choices=["reads", "bins"], help="what is partitioned across ranks (see module docstring)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
@@ -138,13 +139,19 @@ def main():
     log("rank %d: filter built on device + index uploaded in %.1f s" % (rank, time.time() - t0))
 
     t0 = time.time()
-    codes, offs, truth = synth.simulate_reads(genomes, wl["reads"], wl["L"], seed=shard_seed(2, rank))
+    if args.paired:
+        if args.shard == "bins":
+            raise SystemExit("--paired needs --shard reads (pairing over sharded bins is not implemented)")
+        codes, offs, ptruth = synth.simulate_pairs(genomes, wl["reads"] // 2, wl["L"], seed=shard_seed(4, rank))
+        truth = np.zeros(wl["reads"], dtype=[("bin", "<u4")]); truth["bin"] = np.concatenate([ptruth["bin"], ptruth["bin"]])
+    else:
+        codes, offs, truth = synth.simulate_reads(genomes, wl["reads"], wl["L"], seed=shard_seed(2, rank))
     reads = dy.Reads(ctx, codes, offs)
     del genomes
     log("rank %d: %d reads simulated + uploaded in %.1f s" % (rank, wl["reads"], time.time() - t0))
 
     error_rate = np.float32(wl["e"] / 100.0)
-    params = dy.default_params(error_rate=error_rate)
+    params = dy.default_params(error_rate=error_rate, paired=1 if args.paired else 0)
     thr = dy.threshold(error_rate, wl["k"], wl["L"])
 
     def step():
@@ -204,7 +211,7 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wl["desc"], "reads_per_gpu_per_step": wl["reads"], "parallelism": ("reads sharded x%d, filter+index replicated" % world) if sm is None else
+            "config": {"workload": wl["desc"] + (" — PAIRED: %d pairs per step, insert N(400,40)" % (wl["reads"] // 2) if args.paired else ""), "reads_per_gpu_per_step": wl["reads"], "parallelism": ("reads sharded x%d, filter+index replicated" % world) if sm is None else
                                       ("bins sharded x%d (bin mod N), filter+contigs replicated, reads->owners and raw matches->home by all-to-all" % world),
                        "mapped_fraction": mapped_fraction, "primary_in_true_bin": ok_bin,
                        "items_per_read": (stats["items"] if sm is None else sm.last["items"] / world) / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
@@ -215,7 +222,9 @@ def main():
                                  ("every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87% busy at the same time (profiles/r01f_pmc_sq_config2.json)"
                                   if W == 1 else "W = %d words per hash position are fetched by adjacent lanes (k_ibf_query_wide); bound by vector-ALU issue, see DESIGN.md" % W)},
         }
-        if args.cpu_sample > 0 and world == 1:
+        if args.paired:
+            out["config"]["paired_fraction"] = float(rr["paired"].mean())
+        if args.cpu_sample > 0 and world == 1 and not args.paired:
             fpath = os.path.join(work_dir, "bench.filter")
             ibf.save(fpath)
             base, oreads = cpu_baseline(wl, idx_dir, fpath, codes, offs, error_rate, args.cpu_sample)
