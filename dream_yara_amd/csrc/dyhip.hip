@@ -391,17 +391,35 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             }
             ctx->alignList.reserve((size_t)nReads * 4 + 64);
             u32 * peAlignCount = ctx->counters.as<u32>() + 9;
+            ctx->smallList.reserve((size_t)nReads * 4 + 64);
+            u32 * peSmallCount = ctx->counters.as<u32>() + 10;
             hipLaunchKernelGGL(k_pe_route, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, V, ctx->peMStart.as<u32>(), ctx->complexList.as<u32>(), complexCount,
-                               ctx->alignList.as<u32>(), peAlignCount);
+                               ctx->alignList.as<u32>(), peAlignCount, ctx->smallList.as<u32>(), peSmallCount);
             {
                 const bool narrowBand = maxMatchErr <= 3;
                 const u32 traceRows = std::min<u32>(reads->maxLen, THREAD_DP_MAX_LEN) + 1;
                 const u32 dpThreads = (size_t)traceRows * 64 * (narrowBand ? 4 : 8) > 60 * 1024 ? 32 : 64;
                 const size_t traceLds = (size_t)traceRows * dpThreads * (narrowBand ? 4 : 8);
-                if (narrowBand) hipLaunchKernelGGL((k_pe_align_single<3, u32>), dim3(4096), dim3(dpThreads), traceLds, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
-                else hipLaunchKernelGGL((k_pe_align_single<7, u64>), dim3(4096), dim3(dpThreads), traceLds, st, fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+                // like the single-end stage: the list kernels touch disjoint reads and run side by side
+                HIP_CHECK(hipEventRecord(ctx->evFork, st));
+                HIP_CHECK(hipStreamWaitEvent(ctx->side[0], ctx->evFork, 0));
+                HIP_CHECK(hipStreamWaitEvent(ctx->side[1], ctx->evFork, 0));
+                if (narrowBand)
+                {
+                    hipLaunchKernelGGL((k_pe_align_single<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+                    hipLaunchKernelGGL((k_pe_finalize_small<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[1], fa, V, ctx->peMStart.as<u32>(), ctx->smallList.as<u32>(), peSmallCount);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((k_pe_align_single<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+                    hipLaunchKernelGGL((k_pe_finalize_small<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[1], fa, V, ctx->peMStart.as<u32>(), ctx->smallList.as<u32>(), peSmallCount);
+                }
+                HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
+                HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
             }
             hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
+            HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
+            HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
         }
         HIP_CHECK(hipGetLastError());
 }

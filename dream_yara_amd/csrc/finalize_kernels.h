@@ -891,6 +891,108 @@ __device__ __forceinline__ void insertionSortIdx(u32 * idx, u32 cnt, TLess less)
     }
 }
 
+// The child / main aggregation of one read with at most SMALL_T raw matches, in one thread.  `ro` comes initialised (set / cigar
+// offsets, paired-end fields) and is written at the end.  primaryOf(bin, nOpt) names the child's primary: {true, i} = the i-th
+// co-optimal entry (single-end: the child's own random pick), {false, i} = the i-th unique entry in coordinate order (paired-end:
+// the pairing stage has chosen).
+struct SmallPrimary { bool amongOptimal; u32 index; };
+template <int EMAX, typename TRow, typename TPrimaryOf>
+__device__ inline void finalizeSmallRead(const FinalizeArgs & A, u32 read, ReadOut & ro, TRow * trace, u32 traceStride, TPrimaryOf primaryOf)
+{
+    const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+    const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+    const u8 * seq = A.readSeqs + A.readOffs[read];
+    RawMatch E[SMALL_T], M[3 * SMALL_T];
+    u32 idxA[SMALL_T], idxB[SMALL_T], idxM[3 * SMALL_T], idxF[3 * SMALL_T];
+    for (u32 i = 0; i < n; ++i) { E[i] = A.gp[s0 + i]; idxA[i] = i; }
+    insertionSortIdx(idxA, n, [&](u32 a, u32 b) { return lessEnd(E[a], a, E[b], b); });
+    u32 nM = 0, winErr = 256, winRank = 0;
+    u32 p0 = 0;
+    while (p0 < n)
+    {
+        const u32 bin = E[idxA[p0]].bin;
+        u32 p1 = p0 + 1;
+        while (p1 < n && E[idxA[p1]].bin == bin) ++p1;
+        u32 n1 = 0;
+        for (u32 p = p0; p < p1; ++p)
+        {
+            const bool first = p == p0 || !(sameBinContigStrand(E[idxA[p]], E[idxA[p - 1]]) && mEnd(E[idxA[p]]) == mEnd(E[idxA[p - 1]]));
+            if (first) idxB[n1++] = idxA[p];
+        }
+        for (u32 p = p0 + n1; p < p1; ++p) M[nM++] = E[idxA[p]];          // stale tail of pass 1
+        insertionSortIdx(idxB, n1, [&](u32 a, u32 b) { return lessBegin(E[a], a, E[b], b); });
+        u32 n2 = 0, minErr = 255, nOptB = 0;
+        u32 firstMask = 0;
+        for (u32 q = 0; q < n1; ++q)
+        {
+            const bool first = q == 0 || !(sameBinContigStrand(E[idxB[q]], E[idxB[q - 1]]) && E[idxB[q]].begin == E[idxB[q - 1]].begin);
+            if (first) { firstMask |= 1u << q; ++n2; if (E[idxB[q]].errors < minErr) minErr = E[idxB[q]].errors; }
+        }
+        for (u32 q = n2; q < n1; ++q) M[nM++] = E[idxB[q]];               // stale tail of pass 2
+        for (u32 q = 0; q < n1; ++q) if ((firstMask >> q & 1) && E[idxB[q]].errors == minErr) ++nOptB;
+        const SmallPrimary prim = primaryOf(bin, nOptB);
+        const u32 binRank = A.binOrderRank[bin] + 1;
+        u32 optSeen = 0, uniqueSeen = 0;
+        for (u32 q = 0; q < n1; ++q)
+        {
+            if (!(firstMask >> q & 1)) continue;
+            RawMatch a = E[idxB[q]];
+            bool isPrimary;
+            if (prim.amongOptimal) isPrimary = a.errors == minErr && optSeen++ == prim.index;
+            else isPrimary = uniqueSeen == prim.index;
+            ++uniqueSeen;
+            if (isPrimary)
+            {   // the child's primary: CIGAR provenance (copyCigars) + alignMatches
+                const u32 primErr = a.errors;
+                const bool winner = primErr < winErr || (primErr == winErr && binRank > winRank);
+                const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
+                if (gapped)
+                {
+                    const BinDesc & bd = A.bins[a.bin];
+                    const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+                    int cb, ce;
+                    const u32 nc = alignMatchThread<EMAX, TRow>(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors,
+                                                                winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, trace, traceStride);
+                    if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+                    a.begin += (u32)cb; a.len = (u16)ce;
+                }
+                else if (winner) { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
+                if (winner) { winErr = primErr; winRank = binRank; }
+            }
+            M[nM++] = a;
+        }
+        p0 = p1;
+    }
+    // main mapper
+    for (u32 i = 0; i < nM; ++i) idxM[i] = i;
+    insertionSortIdx(idxM, nM, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
+    u32 m1 = 0;
+    for (u32 p = 0; p < nM; ++p)
+        if (p == 0 || !(sameBinContigStrand(M[idxM[p]], M[idxM[p - 1]]) && mEnd(M[idxM[p]]) == mEnd(M[idxM[p - 1]]))) idxF[m1++] = idxM[p];
+    insertionSortIdx(idxF, m1, [&](u32 a, u32 b) { return lessBegin(M[a], a, M[b], b); });
+    u32 m2 = 0;
+    for (u32 q = 0; q < m1; ++q)
+        if (q == 0 || !(sameBinContigStrand(M[idxF[q]], M[idxF[q - 1]]) && M[idxF[q]].begin == M[idxF[q - 1]].begin)) idxM[m2++] = idxF[q];
+    insertionSortIdx(idxM, m2, [&](u32 a, u32 b) { return lessErrors(M[a], a, M[b], b); });
+    const u32 minE = M[idxM[0]].errors, strata = readStrataOf(readLen, A.strataRate);
+    u32 nOpt = 0, nSet = 0;
+    for (u32 q = 0; q < m2; ++q) { const u32 e = M[idxM[q]].errors; nOpt += e == minE; nSet += e <= minE + strata; }
+    const u32 pick = libcxxFirstUniform(nOpt);
+    for (u32 q = 0; q < nSet; ++q)
+    {
+        const RawMatch a = M[idxM[q]];
+        OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
+        A.outSet[(size_t)ro.setBegin + q] = om;
+        if (q == pick)
+        {
+            ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
+            ro.mapped = a.len != 0;
+        }
+    }
+    ro.bestCount = nOpt; ro.subCount = nSet - nOpt;
+    A.out[read] = ro;
+}
+
 template <int EMAX, typename TRow>
 __global__ __launch_bounds__(64) void k_finalize_small(FinalizeArgs A, const u32 * __restrict__ smallList, const u32 * __restrict__ smallCount)
 {
@@ -900,94 +1002,8 @@ __global__ __launch_bounds__(64) void k_finalize_small(FinalizeArgs A, const u32
     for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
     {
         const u32 read = smallList[li];
-        const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
-        const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
-        const u8 * seq = A.readSeqs + A.readOffs[read];
-        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
-        RawMatch E[SMALL_T], M[3 * SMALL_T];
-        u32 idxA[SMALL_T], idxB[SMALL_T], idxM[3 * SMALL_T], idxF[3 * SMALL_T];
-        for (u32 i = 0; i < n; ++i) { E[i] = A.gp[s0 + i]; idxA[i] = i; }
-        insertionSortIdx(idxA, n, [&](u32 a, u32 b) { return lessEnd(E[a], a, E[b], b); });
-        u32 nM = 0, winErr = 256, winRank = 0;
-        u32 p0 = 0;
-        while (p0 < n)
-        {
-            const u32 bin = E[idxA[p0]].bin;
-            u32 p1 = p0 + 1;
-            while (p1 < n && E[idxA[p1]].bin == bin) ++p1;
-            u32 n1 = 0;
-            for (u32 p = p0; p < p1; ++p)
-            {
-                const bool first = p == p0 || !(sameBinContigStrand(E[idxA[p]], E[idxA[p - 1]]) && mEnd(E[idxA[p]]) == mEnd(E[idxA[p - 1]]));
-                if (first) idxB[n1++] = idxA[p];
-            }
-            for (u32 p = p0 + n1; p < p1; ++p) M[nM++] = E[idxA[p]];          // stale tail of pass 1
-            insertionSortIdx(idxB, n1, [&](u32 a, u32 b) { return lessBegin(E[a], a, E[b], b); });
-            u32 n2 = 0, minErr = 255, nOptB = 0;
-            u32 firstMask = 0;
-            for (u32 q = 0; q < n1; ++q)
-            {
-                const bool first = q == 0 || !(sameBinContigStrand(E[idxB[q]], E[idxB[q - 1]]) && E[idxB[q]].begin == E[idxB[q - 1]].begin);
-                if (first) { firstMask |= 1u << q; ++n2; if (E[idxB[q]].errors < minErr) minErr = E[idxB[q]].errors; }
-            }
-            for (u32 q = n2; q < n1; ++q) M[nM++] = E[idxB[q]];               // stale tail of pass 2
-            for (u32 q = 0; q < n1; ++q) if ((firstMask >> q & 1) && E[idxB[q]].errors == minErr) ++nOptB;
-            const u32 pickB = libcxxFirstUniform(nOptB);
-            const u32 binRank = A.binOrderRank[bin] + 1;
-            u32 optSeen = 0;
-            for (u32 q = 0; q < n1; ++q)
-            {
-                if (!(firstMask >> q & 1)) continue;
-                RawMatch a = E[idxB[q]];
-                if (a.errors == minErr && optSeen++ == pickB)
-                {   // the child's primary: CIGAR provenance (copyCigars) + alignMatches
-                    const bool winner = minErr < winErr || (minErr == winErr && binRank > winRank);
-                    const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
-                    if (gapped)
-                    {
-                        const BinDesc & bd = A.bins[a.bin];
-                        const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
-                        int cb, ce;
-                        const u32 nc = alignMatchThread<EMAX, TRow>(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors,
-                                                                    winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, trace, blockDim.x);
-                        if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
-                        a.begin += (u32)cb; a.len = (u16)ce;
-                    }
-                    else if (winner) { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
-                    if (winner) { winErr = minErr; winRank = binRank; }
-                }
-                M[nM++] = a;
-            }
-            p0 = p1;
-        }
-        // main mapper
-        for (u32 i = 0; i < nM; ++i) idxM[i] = i;
-        insertionSortIdx(idxM, nM, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
-        u32 m1 = 0;
-        for (u32 p = 0; p < nM; ++p)
-            if (p == 0 || !(sameBinContigStrand(M[idxM[p]], M[idxM[p - 1]]) && mEnd(M[idxM[p]]) == mEnd(M[idxM[p - 1]]))) idxF[m1++] = idxM[p];
-        insertionSortIdx(idxF, m1, [&](u32 a, u32 b) { return lessBegin(M[a], a, M[b], b); });
-        u32 m2 = 0;
-        for (u32 q = 0; q < m1; ++q)
-            if (q == 0 || !(sameBinContigStrand(M[idxF[q]], M[idxF[q - 1]]) && M[idxF[q]].begin == M[idxF[q - 1]].begin)) idxM[m2++] = idxF[q];
-        insertionSortIdx(idxM, m2, [&](u32 a, u32 b) { return lessErrors(M[a], a, M[b], b); });
-        const u32 minE = M[idxM[0]].errors, strata = readStrataOf(readLen, A.strataRate);
-        u32 nOpt = 0, nSet = 0;
-        for (u32 q = 0; q < m2; ++q) { const u32 e = M[idxM[q]].errors; nOpt += e == minE; nSet += e <= minE + strata; }
-        const u32 pick = libcxxFirstUniform(nOpt);
-        for (u32 q = 0; q < nSet; ++q)
-        {
-            const RawMatch a = M[idxM[q]];
-            OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
-            A.outSet[(size_t)ro.setBegin + q] = om;
-            if (q == pick)
-            {
-                ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
-                ro.mapped = a.len != 0;
-            }
-        }
-        ro.bestCount = nOpt; ro.subCount = nSet - nOpt;
-        A.out[read] = ro;
+        ReadOut ro; initReadOut(ro, 3 * A.readStart[read], read * A.cigarStride);
+        finalizeSmallRead<EMAX, TRow>(A, read, ro, trace, blockDim.x, [](u32, u32 nOptB) { return SmallPrimary{true, libcxxFirstUniform(nOptB)}; });
     }
 }
 

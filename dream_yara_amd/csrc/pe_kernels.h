@@ -639,10 +639,10 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
 // and compactions are identities on one entry.  A primary that needs the alignment DP, and every read with more entries,
 // goes to the list of k_pe_finalize.
 __global__ __launch_bounds__(1024) void k_pe_route(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, u32 * __restrict__ list, u32 * __restrict__ listCount,
-                           u32 * __restrict__ alignList, u32 * __restrict__ alignCount)
+                           u32 * __restrict__ alignList, u32 * __restrict__ alignCount, u32 * __restrict__ smallList, u32 * __restrict__ smallCount)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
-    bool complex = false, align = false;
+    bool complex = false, align = false, small = false;
     if (read < A.nReads)
     {
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
@@ -661,6 +661,11 @@ __global__ __launch_bounds__(1024) void k_pe_route(FinalizeArgs A, PeView V, con
                 const u64 m = V.masks[(size_t)read * V.W + w];
                 if (m) bin = w * 64 + (u32)(__ffsll((long long)m) - 1);
                 nSel += (u32)__popcll(m);
+            }
+            if (nSel == 1 && n >= 2 && n <= SMALL_T && !hasRescue && !(A.debugFlags & 2))
+            {   // a handful of raw matches in the only selected bin: thread-level aggregation (k_pe_finalize_small)
+                const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+                if (readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E) { complex = false; small = true; }
             }
             if (nSel == 1 && n <= 1)
             {
@@ -691,10 +696,31 @@ __global__ __launch_bounds__(1024) void k_pe_route(FinalizeArgs A, PeView V, con
             }
         }
     }
-    const bool want[2] = {complex, align};
-    u32 * const lists[2] = {list, alignList};
-    u32 * const counts[2] = {listCount, alignCount};
-    blockAppend<2>(want, read, lists, counts);
+    const bool want[3] = {complex, align, small};
+    u32 * const lists[3] = {list, alignList, smallList};
+    u32 * const counts[3] = {listCount, alignCount, smallCount};
+    blockAppend<3>(want, read, lists, counts);
+}
+
+// Reads with 2..SMALL_T raw matches, all in the only selected bin: one thread each (see finalizeSmallRead); the child's primary
+// is the one the pairing stage left in PeItem::primary.
+template <int EMAX, typename TRow>
+__global__ __launch_bounds__(64) void k_pe_finalize_small(FinalizeArgs A, PeView V, const u32 * __restrict__ mStart, const u32 * __restrict__ smallList,
+                                                          const u32 * __restrict__ smallCount)
+{
+    extern __shared__ u64 dpTraceLds[];
+    TRow * trace = (TRow *)dpTraceLds + threadIdx.x;
+    const u32 nList = *smallCount;
+    for (u32 li = blockIdx.x * blockDim.x + threadIdx.x; li < nList; li += gridDim.x * blockDim.x)
+    {
+        const u32 read = smallList[li];
+        u32 bin = 0;
+        for (u32 w = 0; w < V.W; ++w) { const u64 m = V.masks[(size_t)read * V.W + w]; if (m) bin = w * 64 + (u32)(__ffsll((long long)m) - 1); }
+        const PeItem it = V.items[peFindItem(V, read, bin)];
+        ReadOut ro; initReadOut(ro, mStart[read], read * A.cigarStride);
+        ro.paired = it.paired ? 1 : 0; ro.pairProb = it.paired ? it.prob : 0.0;
+        finalizeSmallRead<EMAX, TRow>(A, read, ro, trace, blockDim.x, [&](u32, u32) { return SmallPrimary{false, it.primary}; });
+    }
 }
 
 // Single-entry reads whose primary needs the alignment DP (thread-level DP, all lanes busy)
