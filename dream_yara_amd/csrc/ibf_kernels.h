@@ -234,14 +234,19 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
                     else if (base == 64) m0 = cached1;
                     else m0 = valid ? words[ibfWordIndex(g, hash, 0) + w] : 0;
                     const bool has0 = valid && ((m0 >> j) & 1);
-                    for (u32 half = 0; half < 2 && open; ++half)
+                    // verify only as many k-mers at a time as are still needed to reach the threshold (29 of the 64 for a clean read)
+                    u64 pending = ballot64(has0);
+                    while (pending && open)
                     {
-                        const bool act = has0 && (lane >> 5) == half;
+                        const u32 need = threshold - exactCnt;
+                        const bool act = ((pending >> lane) & 1) && (u32)__popcll(pending & ((1ull << lane) - 1)) < need;
                         bool hit = act;
                         if (act)
                             for (u32 hf = 1; hf < g.nHashes; ++hf) hit &= (words[ibfWordIndex(g, hash, hf) + w] >> j) & 1;
+                        const u64 actMask = ballot64(act);
                         exactCnt += (u32)__popcll(ballot64(hit));
-                        seenCnt += (u32)__popcll(ballot64(act));
+                        seenCnt += (u32)__popcll(actMask);
+                        pending &= ~actMask;
                         if (exactCnt >= threshold) { selW |= 1ull << j; open = false; }
                         else if (exactCnt + (bound0 - seenCnt) < threshold) open = false;
                     }
