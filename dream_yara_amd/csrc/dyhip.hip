@@ -84,7 +84,7 @@ struct dy_ctx
     DevBuf peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList;
+           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
     size_t poolCap = 0;
     DevBuf spare[6];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
@@ -185,7 +185,7 @@ template <int NW>
 static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink)
 {
     hipLaunchKernelGGL(k_extend<NW>, dim3(((nItems + 255) / 256 + 7) / 8 * 8), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
-                       nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>());
+                       nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>());
     // re-seeded items: list-driven, spread thinly over a full grid (normally a tiny fraction of the items)
     hipLaunchKernelGGL(k_extend_hard<NW>, dim3(2048), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(),
                        ctx->itemBin.as<u16>(), S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>());
@@ -233,6 +233,24 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             u64 threads = (u64)nItems * 2 * S0;
             hipLaunchKernelGGL(k_seed_search, dim3((u32)(((threads + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
                                nItems, S0, mp.errorRate, ctx->hits0.as<uint2>());
+        }
+        // ---- K3 work order: (bin, seeds found)
+        ctx->itemKeys.reserve((size_t)nItems * 4 + 64); ctx->itemPerm.reserve((size_t)nItems * 4 + 64);
+        {
+            const size_t nKeys = (size_t)nBins * 8 + 1;
+            ctx->orderHist.reserve(nKeys * 4 + 64); ctx->orderCursor.reserve(nKeys * 4 + 64);
+            if (nItems)
+            {
+                HIP_CHECK(hipMemsetAsync(ctx->orderHist.p, 0, nKeys * 4, st));
+                hipLaunchKernelGGL(k_item_order_count, dim3((nItems + 1023) / 1024), dim3(1024), 0, st, ctx->hits0.as<uint2>(), ctx->itemBin.as<u16>(), nItems, S0,
+                                   ctx->itemKeys.as<u32>(), ctx->orderHist.as<u32>());
+                size_t tb = 0;
+                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ctx->orderHist.as<u32>(), ctx->orderCursor.as<u32>(), (int)nKeys, st));
+                ctx->scanTmp.reserve(tb + 64);
+                HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->orderHist.as<u32>(), ctx->orderCursor.as<u32>(), (int)nKeys, st));
+                hipLaunchKernelGGL(k_item_order_scatter, dim3((nItems + 1023) / 1024), dim3(1024), 0, st, ctx->itemKeys.as<u32>(), nItems, ctx->orderCursor.as<u32>(),
+                                   ctx->itemPerm.as<u32>());
+            }
         }
         HIP_CHECK(hipEventRecord(ctx->ev[4], st));
 

@@ -495,6 +495,64 @@ __device__ void fmBacktrack(const BinView & b, const u8 * __restrict__ seq, u32 
 // ---------------------------------------------------------------------------------------------------
 // K3: one thread per work item runs the read-local remainder of _mapReadsImpl.
 // ---------------------------------------------------------------------------------------------------
+// ---- K3 work order ---------------------------------------------------------------------------------------------------------
+// A wavefront of k_extend runs as many extension rounds as its slowest lane, and the rounds an item needs follow from how many
+// of its exact seeds were found: all of them -> the read matches without error, one LCP pass, no Myers; each seed that
+// found nothing costs one more rank (the early exit minErrors <= rank) and a Myers call.  Items are therefore processed in
+// the order (bin, number of seeds found): wavefronts become homogeneous.  Only the ORDER changes — itemRead / itemBin / hits0
+// stay as they are, the raw matches are sorted downstream anyway.
+__device__ __forceinline__ u32 itemOrderKey(const uint2 * __restrict__ h0, u32 S0, u32 bin)
+{
+    u32 nf = 0, nr = 0;
+    for (u32 k = 0; k < S0; ++k) { nf += hitCount(h0[k]) != 0; nr += hitCount(h0[S0 + k]) != 0; }
+    const u32 cls = max(nf, nr);
+    return bin * 8 + (cls < 7 ? cls : 7);
+}
+// Slot of every thread's key: counters[key] += (threads of the block with that key), ONE global atomic per key and block.
+// The list is bin-major, so a block sees a handful of consecutive keys: they are counted in an LDS window that starts at the
+// block's smallest key; keys outside the window (pathological: hundreds of tiny bins inside one block) go to the global counter
+// one by one.  Every thread of the block must call this.
+enum { ORDER_WINDOW = 256 };
+__device__ __forceinline__ u32 blockKeySlot(bool valid, u32 key, u32 * __restrict__ counters)
+{
+    __shared__ u32 winCount[ORDER_WINDOW], winBase[ORDER_WINDOW];
+    __shared__ u32 firstKey;
+    if (threadIdx.x == 0) firstKey = 0xFFFFFFFFu;
+    for (u32 i = threadIdx.x; i < ORDER_WINDOW; i += blockDim.x) winCount[i] = 0;
+    __syncthreads();
+    if (valid) atomicMin(&firstKey, key);
+    __syncthreads();
+    const u32 rel = key - firstKey;
+    const bool inWin = valid && rel < ORDER_WINDOW;
+    u32 rank = 0;
+    if (inWin) rank = atomicAdd(&winCount[rel], 1u);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < ORDER_WINDOW; i += blockDim.x) winBase[i] = winCount[i] ? atomicAdd(&counters[firstKey + i], winCount[i]) : 0;
+    __syncthreads();
+    u32 slot = 0;
+    if (inWin) slot = winBase[rel] + rank;
+    else if (valid) slot = atomicAdd(&counters[key], 1u);
+    return slot;
+}
+__global__ __launch_bounds__(1024) void k_item_order_count(const uint2 * __restrict__ hits0, const u16 * __restrict__ itemBin, u32 nItems, u32 S0,
+                                                           u32 * __restrict__ keys, u32 * __restrict__ hist)
+{
+    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = item < nItems;
+    u32 key = 0;
+    if (valid) { key = itemOrderKey(hits0 + (size_t)item * 2 * S0, S0, itemBin[item]); keys[item] = key; }
+    (void)blockKeySlot(valid, key, hist);
+}
+__global__ __launch_bounds__(1024) void k_item_order_scatter(const u32 * __restrict__ keys, u32 nItems, u32 * __restrict__ cursor /* = exclusive scan of hist */,
+                                                             u32 * __restrict__ perm)
+{
+    const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = item < nItems;
+    const u32 key = valid ? keys[item] : 0;
+    const u32 slot = blockKeySlot(valid, key, cursor);
+    if (valid) perm[slot] = item;
+}
+
 // classifyReads for one item (reference src/mapper_classifier.h:111-155): 0 = easy, 1 / 2 = re-seed with that many seed errors
 __device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S0, const MapParams & prm)
 {
@@ -687,14 +745,15 @@ __device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read
 template <int NW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? DY_K3_WAVES : 1, NW <= 2 ? DY_K3_WAVES : 8))) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
                                                 u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
-                                                u32 * __restrict__ hardCount, u32 * __restrict__ hardList)
+                                                u32 * __restrict__ hardCount, u32 * __restrict__ hardList, const u32 * __restrict__ perm)
 {
-    const u32 item = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const u32 idx = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
     ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
     u32 read = 0;
     u32 bin = 0;
-    const bool valid = item < nItems;
+    const bool valid = idx < nItems;
+    const u32 item = valid ? perm[idx] : 0;           // work order: see k_item_order_*
     if (valid) { read = itemRead[item]; bin = itemBin[item]; }
     extendEasyItem<NW>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardCount, hardList, st, valid);
     flushBlockMatches(st, read, sink, lane);
