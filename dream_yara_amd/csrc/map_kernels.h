@@ -43,10 +43,22 @@ __device__ __forceinline__ u64 mismatchFlags(u64 a, u64 b)
     x |= (x >> 1) | (x >> 2);
     return x & 0x0101010101010101ull;
 }
-// length of the common prefix of a[0..n) and b[0..n)
+// length of the common prefix of a[0..n) and b[0..n).  32 bytes per step with all eight loads issued before the first compare:
+// the loop is a chain of dependent memory round trips (the early exit keeps the compiler from hoisting loads), and K3 is bound
+// by exactly that latency.
 __device__ __forceinline__ int lcpForward(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
 {
     int i = 0;
+    for (; i + 32 <= n; i += 32)
+    {
+        const u64 a0 = load8(a + i), a1 = load8(a + i + 8), a2 = load8(a + i + 16), a3 = load8(a + i + 24);
+        const u64 b0 = load8(b + i), b1 = load8(b + i + 8), b2 = load8(b + i + 16), b3 = load8(b + i + 24);
+        const u64 f0 = mismatchFlags(a0, b0), f1 = mismatchFlags(a1, b1), f2 = mismatchFlags(a2, b2), f3 = mismatchFlags(a3, b3);
+        if (f0) return i + (__ffsll((long long)f0) - 1) / 8;
+        if (f1) return i + 8 + (__ffsll((long long)f1) - 1) / 8;
+        if (f2) return i + 16 + (__ffsll((long long)f2) - 1) / 8;
+        if (f3) return i + 24 + (__ffsll((long long)f3) - 1) / 8;
+    }
     for (; i + 8 <= n; i += 8)
     {
         const u64 f = mismatchFlags(load8(a + i), load8(b + i));
@@ -59,6 +71,16 @@ __device__ __forceinline__ int lcpForward(const u8 * __restrict__ a, const u8 * 
 __device__ __forceinline__ int lcpBackward(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
 {
     int i = 0;
+    for (; i + 32 <= n; i += 32)
+    {
+        const u64 a0 = load8(a - i - 8), a1 = load8(a - i - 16), a2 = load8(a - i - 24), a3 = load8(a - i - 32);
+        const u64 b0 = load8(b - i - 8), b1 = load8(b - i - 16), b2 = load8(b - i - 24), b3 = load8(b - i - 32);
+        const u64 f0 = mismatchFlags(a0, b0), f1 = mismatchFlags(a1, b1), f2 = mismatchFlags(a2, b2), f3 = mismatchFlags(a3, b3);
+        if (f0) return i + __clzll((long long)f0) / 8;
+        if (f1) return i + 8 + __clzll((long long)f1) / 8;
+        if (f2) return i + 16 + __clzll((long long)f2) / 8;
+        if (f3) return i + 24 + __clzll((long long)f3) / 8;
+    }
     for (; i + 8 <= n; i += 8)
     {
         const u64 f = mismatchFlags(load8(a - i - 8), load8(b - i - 8));
