@@ -374,11 +374,12 @@ struct MatchSink
 // extend() + _addMatchImpl() for one located seed occurrence (reference src/find_extender.h:262-403, src/mapper_extender.h:293-308).
 // `seq` is the read sequence of the seed's strand (forward or reverse complement), readable front to back.
 template <int NW>
-__device__ void extendOccurrence(const BinView & b, u32 contig, u32 hayBegin, u32 seedLen, const u8 * __restrict__ seq, u32 len, u32 strand,
+__device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
+                                 const u8 * __restrict__ seq, u32 len, u32 strand,
                                  u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
 {
-    const u8 * __restrict__ ctg = b.contigs + b.limits[contig];
-    const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+    const u8 * __restrict__ ctg = binContigs + binLimits[contig];
+    const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
     const u32 hayEnd = hayBegin + seedLen, needleEnd = needleBegin + seedLen;
     // _checkSeed: recount against the real contig (Ns were randomised in the index); the early-out of the reference's
     // loop only matters when the total exceeds maxErrors, which fails either way
@@ -476,7 +477,7 @@ __device__ void extendRange(const BinView & b, u32 lo, u32 hi, u32 seedLen, cons
         if (sink.debugFlags & 1) { if (x == 0xFFFFFFFFu) st.minErrors = 0; continue; }
         const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
         if (clen - x < seedLen) continue;                       // suffixLength < seedLength
-        extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, seq, len, strand, needleBegin, maxErrors, read, bin, st, sink);
+        extendOccurrence<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, seq, len, strand, needleBegin, maxErrors, read, bin, st, sink);
     }
 }
 
@@ -595,7 +596,9 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
 {
     const u8 * seq = nullptr, * seqRc = nullptr;
     u32 len = 0, readErrors = 0, readStrata = 0, cnt0 = 1, seedErrors = 0;
-    BinView b;
+    // only what the extension itself needs stays live per lane (the full BinView costs ~25 VGPRs; a row that still has to be
+    // located — a seed with several occurrences — rebuilds it on the spot)
+    const u8 * binContigs = nullptr; const u64 * binLimits = nullptr;
     const uint2 * h0 = hits0;
     if (valid)
     {
@@ -603,7 +606,7 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
         seqRc = rd.seqsRc + rd.offs[read];
         len = (u32)(rd.offs[read + 1] - rd.offs[read]);
         readErrors = readErrorsOf(len, prm.errorRate); readStrata = readStrataOf(len, prm.strataRate);
-        b = makeBinView(ix, bin);
+        binContigs = ix.contigs + ix.bins[bin].contigOff; binLimits = ix.limits + ix.bins[bin].limOff;
         h0 = hits0 + (size_t)item * 2 * S0;
         cnt0 = seedCountOf(readErrors, 0);
         seedErrors = classifyItem(h0, S0, prm);
@@ -647,11 +650,11 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
         if (have && !(sink.debugFlags & 2))
         {   // _extendHitImpl for one SA row (reference src/mapper_extender.h:263-285)
             u32 contig, x;
-            if (direct) { contig = directContig; x = directX; } else fmLocate(b, row, contig, x);
+            if (direct) { contig = directContig; x = directX; } else fmLocate(makeBinView(ix, bin), row, contig, x);
             ++row;
-            const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+            const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
             if (clen - x >= seedLen && !(sink.debugFlags & 1))
-                extendOccurrence<NW>(b, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
+                extendOccurrence<NW>(binContigs, binLimits, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
         }
         else if (have) ++row;
     }
