@@ -86,7 +86,7 @@ struct dy_ctx
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
     size_t poolCap = 0;
-    DevBuf spare[6];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
+    DevBuf spare[12];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
     u32 lastRaw = 0; bool rawValid = false;
@@ -96,7 +96,7 @@ struct dy_ctx
 static void takeBuffer(dy_ctx * ctx, DevBuf & d, size_t bytes)
 {
     int best = -1;
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 12; ++i)
         if (ctx->spare[i].p && ctx->spare[i].cap >= bytes && (best < 0 || ctx->spare[i].cap < ctx->spare[best].cap)) best = i;
     if (best >= 0) ctx->spare[best].moveTo(d);
     else d.reserve(bytes);
@@ -105,8 +105,8 @@ static void giveBuffer(dy_ctx * ctx, DevBuf & d)
 {
     if (!d.p) return;
     int slot = -1;
-    for (int i = 0; i < 6; ++i) if (!ctx->spare[i].p) { slot = i; break; }
-    if (slot < 0) { slot = 0; for (int i = 1; i < 6; ++i) if (ctx->spare[i].cap < ctx->spare[slot].cap) slot = i; if (ctx->spare[slot].cap >= d.cap) return; }
+    for (int i = 0; i < 12; ++i) if (!ctx->spare[i].p) { slot = i; break; }
+    if (slot < 0) { slot = 0; for (int i = 1; i < 12; ++i) if (ctx->spare[i].cap < ctx->spare[slot].cap) slot = i; if (ctx->spare[slot].cap >= d.cap) return; }
     d.moveTo(ctx->spare[slot]);
 }
 
@@ -125,6 +125,7 @@ struct dy_reads
     DevBuf seqs, seqsRc, offs, masks;
     std::shared_ptr<std::vector<u32>> lens = std::make_shared<std::vector<u32>>();   // host copy of the read lengths (MAPQ needs them); shared with results
     u32 maskW = 0;       // words per read currently held in masks (0 = none)
+    bool recycle = false; // buffers came from / go back to the context's spare pool (batches built per step by dy_reads_from_device)
     u32 maskBins = 0;
 };
 
@@ -728,7 +729,13 @@ int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, u
 }
 
 uint32_t dy_reads_count(const dy_reads * r) { return r ? r->n : 0; }
-void dy_reads_free(dy_reads * r) { if (r) { (void)hipSetDevice(r->ctx->device); delete r; } }
+void dy_reads_free(dy_reads * r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->ctx->device);
+    if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); }
+    delete r;
+}
 
 int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bin_masks_host)
 {
@@ -1106,12 +1113,11 @@ int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_
         HIP_CHECK(hipSetDevice(ctx->device));
         std::unique_ptr<dy_reads> r(new dy_reads);
         r->ctx = ctx; r->n = n_reads; r->totalBases = n_bases;
-        r->lens->resize(n_reads);
-        if (n_reads) HIP_CHECK(hipMemcpyAsync(r->lens->data(), lens_dev, (size_t)n_reads * 4, hipMemcpyDeviceToHost, ctx->stream));
-        r->seqs.reserve(n_bases + 64); r->seqsRc.reserve(n_bases + 64);
-        r->offs.reserve((size_t)(n_reads + 1) * 8);
+        r->recycle = true;
+        takeBuffer(ctx, r->seqs, n_bases + 64); takeBuffer(ctx, r->seqsRc, n_bases + 64);
+        takeBuffer(ctx, r->offs, (size_t)(n_reads + 1) * 8);
         const u32 W = (n_bins + 63) / 64;
-        r->masks.reserve((size_t)n_reads * W * 8 + 8);
+        takeBuffer(ctx, r->masks, (size_t)n_reads * W * 8 + 8);
         r->maskW = W; r->maskBins = n_bins;
         if (n_bases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs_dev, n_bases, hipMemcpyDeviceToDevice, ctx->stream));
         if (n_reads) HIP_CHECK(hipMemcpyAsync(r->masks.p, masks_dev, (size_t)n_reads * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1120,10 +1126,16 @@ int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_
         exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
         if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->planReads = nullptr;        // shLen was reused
-        u64 sum = 0; u32 mx = 0, mn = 0xFFFFFFFFu;
-        for (u32 l : *r->lens) { if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded."); sum += l; mx = std::max(mx, l); mn = std::min(mn, l); }
+        // length statistics on the device (the lengths themselves stay there: a batch built this way is searched, never reported)
+        unsigned long long hostStats[3] = {0, 0, ~0ull};
+        ctx->shTotals.reserve(64);
+        HIP_CHECK(hipMemcpyAsync(ctx->shTotals.p, hostStats, 24, hipMemcpyHostToDevice, ctx->stream));
+        if (n_reads) hipLaunchKernelGGL(k_lens_stats, dim3(256), dim3(256), 0, ctx->stream, (const u32 *)lens_dev, n_reads, ctx->shTotals.as<unsigned long long>());
+        HIP_CHECK(hipMemcpyAsync(hostStats, ctx->shTotals.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const u64 sum = hostStats[0]; const u32 mx = (u32)hostStats[1], mn = (u32)hostStats[2];
+        if (mx > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");
         if (sum != n_bases) throw DyError(DY_EINVAL, "dy_reads_from_device: lengths do not add up to n_bases");
         r->maxLen = mx; r->minLen = n_reads ? mn : 0;
         *out = r.release();

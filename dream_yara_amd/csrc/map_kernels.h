@@ -23,14 +23,22 @@ struct ReadsView
     u32         nReads;
 };
 
-// one thread per read writes its reverse complement
+// one thread per read writes its reverse complement, 8 bases per step (byte swap; A<->T, C<->G is code ^ 3, N = 4 stays)
+struct __attribute__((packed)) PackedU64rc { u64 v; };
 __global__ void k_revcomp_reads(const u8 * __restrict__ fwd, u8 * __restrict__ rc, const u64 * __restrict__ offs, u32 nReads)
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nReads) return;
     const u64 o = offs[r];
     const u32 len = (u32)(offs[r + 1] - o);
-    for (u32 i = 0; i < len; ++i) { const u8 c = fwd[o + len - 1 - i]; rc[o + i] = c < 4 ? (u8)(3 - c) : c; }
+    u32 i = 0;
+    for (; i + 8 <= len; i += 8)
+    {
+        const u64 w = __builtin_bswap64(((const PackedU64rc *)(fwd + o + len - 8 - i))->v);
+        const u64 isN = ((w >> 2) & 0x0101010101010101ull) * 0xFFull;
+        ((PackedU64rc *)(rc + o + i))->v = w ^ (0x0303030303030303ull & ~isN);
+    }
+    for (; i < len; ++i) { const u8 c = fwd[o + len - 1 - i]; rc[o + i] = c < 4 ? (u8)(3 - c) : c; }
 }
 
 // ---- 8-bytes-at-a-time comparison of Dna5 code strings (N = 4 never matches, reference src/basic_alphabet.h:47) ----

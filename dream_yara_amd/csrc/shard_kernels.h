@@ -67,6 +67,20 @@ __global__ void k_widen_lens(const u32 * __restrict__ lens, u32 n, u64 * __restr
     if (t <= n) out[t] = t < n ? lens[t] : 0;
 }
 
+// stats[0] = sum, stats[1] = max, stats[2] = min of the lengths (stats pre-set to {0, 0, ~0})
+__global__ void k_lens_stats(const u32 * __restrict__ lens, u32 n, unsigned long long * __restrict__ stats)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s = 0; u32 mx = 0, mn = 0xFFFFFFFFu;
+    for (u32 i = t; i < n; i += gridDim.x * blockDim.x) { const u32 l = lens[i]; s += l; mx = max(mx, l); mn = min(mn, l); }
+    for (int o = 32; o >= 1; o >>= 1)
+    {
+        s += ((u64)__shfl_xor((u32)(s >> 32), o, 64) << 32) | __shfl_xor((u32)s, o, 64);
+        mx = max(mx, (u32)__shfl_xor(mx, o, 64)); mn = min(mn, (u32)__shfl_xor(mn, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stats[0], s); atomicMax(&stats[1], (unsigned long long)mx); atomicMin(&stats[2], (unsigned long long)mn); }
+}
+
 __global__ void k_and_masks(u64 * __restrict__ masks, u32 n, u32 W, const u64 * __restrict__ allowed)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
