@@ -62,6 +62,25 @@ struct DevBuf
     void moveTo(DevBuf & o) { if (o.p) (void)hipFree(o.p); o.p = p; o.cap = cap; p = nullptr; cap = 0; }
 };
 
+// grow-only pinned host buffer (D2H of the results runs at PCIe speed instead of through the pageable-memory staging path)
+struct PinnedBuf
+{
+    void * p = nullptr; size_t cap = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf & operator=(const PinnedBuf &) = delete;
+    void reserve(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+    }
+    template <typename T> T * as() const { return (T *)p; }
+};
+
 int deviceCount()
 {
     int n = 0;
@@ -86,6 +105,7 @@ struct dy_ctx
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
     size_t poolCap = 0;
+    PinnedBuf hostOut, hostSet, hostCigars;     // staging of dy_result_fetch
     DevBuf spare[12];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
@@ -987,15 +1007,23 @@ int dy_result_fetch(dy_result * r)
         if (r->fetched) return;
         dy_ctx * ctx = r->ctx;
         HIP_CHECK(hipSetDevice(ctx->device));
-        std::vector<ReadOut> ro(r->nReads);
-        std::vector<OutMatch> os(r->setCap);
-        std::vector<u32> cg((size_t)r->nReads * r->cigarStride);
-        if (r->nReads) HIP_CHECK(hipMemcpyAsync(ro.data(), r->out.p, ro.size() * sizeof(ReadOut), hipMemcpyDeviceToHost, ctx->stream));
-        if (!os.empty()) HIP_CHECK(hipMemcpyAsync(os.data(), r->outSet.p, os.size() * sizeof(OutMatch), hipMemcpyDeviceToHost, ctx->stream));
-        if (!cg.empty()) HIP_CHECK(hipMemcpyAsync(cg.data(), r->cigars.p, cg.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        const size_t nCigarWords = (size_t)r->nReads * r->cigarStride;
+        ctx->hostOut.reserve((size_t)r->nReads * sizeof(ReadOut) + 64); ctx->hostSet.reserve(r->setCap * sizeof(OutMatch) + 64);
+        ctx->hostCigars.reserve(nCigarWords * 4 + 64);
+        const ReadOut * ro = ctx->hostOut.as<ReadOut>(); const OutMatch * os = ctx->hostSet.as<OutMatch>(); const u32 * cg = ctx->hostCigars.as<u32>();
+        if (r->nReads) HIP_CHECK(hipMemcpyAsync(ctx->hostOut.p, r->out.p, (size_t)r->nReads * sizeof(ReadOut), hipMemcpyDeviceToHost, ctx->stream));
+        if (r->setCap) HIP_CHECK(hipMemcpyAsync(ctx->hostSet.p, r->outSet.p, r->setCap * sizeof(OutMatch), hipMemcpyDeviceToHost, ctx->stream));
+        if (nCigarWords) HIP_CHECK(hipMemcpyAsync(ctx->hostCigars.p, r->cigars.p, nCigarWords * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         r->reads.resize(r->nReads);
         r->matches.clear(); r->cigarOps.clear();
+        size_t nMatches = 0, nOps = 0;
+        for (u32 i = 0; i < r->nReads; ++i) { nMatches += ro[i].bestCount + ro[i].subCount; nOps += ro[i].mapped ? ro[i].cigarLen : 0; }
+        r->matches.reserve(nMatches); r->cigarOps.reserve(nOps);
+        // MAPQ is a pure function of (errors, read length, best, sub): a small memo covers nearly every read (3 pow + 1 log10 each otherwise)
+        enum { MEMO_E = 16, MEMO_C = 8 };
+        u32 memoLen = 0; int memo[MEMO_E][MEMO_C][MEMO_C];
+        for (auto & a : memo) for (auto & b : a) for (auto & c : b) c = -1;
         for (u32 i = 0; i < r->nReads; ++i)
         {
             const ReadOut & o = ro[i];
@@ -1003,8 +1031,20 @@ int dy_result_fetch(dy_result * r)
             d.primary.contig = o.contig; d.primary.begin = o.begin; d.primary.length = o.length; d.primary.errors = o.errors; d.primary.is_rev = o.isRev;
             d.mapped = o.mapped; d.best_count = o.bestCount; d.sub_count = o.subCount;
             d.paired = o.paired; d.reserved = 0; d.pair_prob = o.pairProb;
-            d.mapq = !o.mapped ? 0 : o.paired ? (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(o.pairProb, 0.9999999)))
-                                              : mapqOf(o.errors, (*r->readLens)[i], o.bestCount, o.subCount);
+            if (!o.mapped) d.mapq = 0;
+            else if (o.paired) d.mapq = (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(o.pairProb, 0.9999999)));
+            else
+            {
+                const u32 len = (*r->readLens)[i];
+                if (len != memoLen) { memoLen = len; for (auto & a : memo) for (auto & b : a) for (auto & c : b) c = -1; }
+                if (o.errors < MEMO_E && o.bestCount < MEMO_C && o.subCount < MEMO_C)
+                {
+                    int & m = memo[o.errors][o.bestCount][o.subCount];
+                    if (m < 0) m = (int)mapqOf(o.errors, len, o.bestCount, o.subCount);
+                    d.mapq = (unsigned)m;
+                }
+                else d.mapq = mapqOf(o.errors, len, o.bestCount, o.subCount);
+            }
             d.set_begin = (u32)r->matches.size();
             u32 nset = o.bestCount + o.subCount;
             for (u32 k = 0; k < nset; ++k)
