@@ -10,6 +10,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <thread>
+#include <algorithm>
 
 namespace dy {
 
@@ -29,6 +31,26 @@ public:
         }
     }
     template <typename T> void put(T v) { write(&v, sizeof(T)); }      // little-endian host
+    // Same stream as write(data, n), but the 64 KiB blocks are deflated by `threads` workers (BGZF blocks are independent).
+    void writeParallel(const uint8_t * data, size_t n, unsigned threads)
+    {
+        if (!buf_.empty()) { size_t take = std::min(n, kBlock - buf_.size()); write(data, take); data += take; n -= take; }
+        const size_t nBlocks = n / kBlock;
+        if (nBlocks < 2 || threads < 2) { write(data, n); return; }
+        std::vector<std::vector<uint8_t>> outBlocks(nBlocks);
+        std::vector<std::thread> pool;
+        const unsigned T = (unsigned)std::min<size_t>(threads, nBlocks);
+        std::vector<std::string> errors(T);
+        for (unsigned t = 0; t < T; ++t)
+            pool.emplace_back([&, t] {
+                try { for (size_t b = t; b < nBlocks; b += T) compressBlock(data + b * kBlock, kBlock, outBlocks[b]); }
+                catch (std::exception const & e) { errors[t] = e.what(); }
+            });
+        for (auto & th : pool) th.join();
+        for (auto & e : errors) if (!e.empty()) throw std::runtime_error(e);
+        for (auto & ob : outBlocks) os_.write((const char *)ob.data(), (std::streamsize)ob.size());
+        write(data + nBlocks * kBlock, n - nBlocks * kBlock);
+    }
     void finish()
     {
         if (!buf_.empty()) flushBlock();
@@ -38,23 +60,29 @@ public:
     }
 private:
     static constexpr size_t kBlock = 0xff00;       // payload per block, leaves room for incompressible data
-    void flushBlock()
+    static void compressBlock(const uint8_t * in, size_t n, std::vector<uint8_t> & out)
     {
-        uint8_t out[0x10000 + 64];
+        out.resize(0x10000 + 64);
         z_stream zs; memset(&zs, 0, sizeof zs);
         if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib: deflateInit2 failed");
-        zs.next_in = buf_.data(); zs.avail_in = (uInt)buf_.size();
-        zs.next_out = out + 18; zs.avail_out = sizeof(out) - 18 - 8;
+        zs.next_in = const_cast<uint8_t *>(in); zs.avail_in = (uInt)n;
+        zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 18 - 8);
         if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("zlib: deflate failed"); }
         const size_t clen = zs.total_out;
         deflateEnd(&zs);
         const size_t bsize = clen + 18 + 8;
         if (bsize > 0x10000) throw std::runtime_error("BGZF block too large");
         const uint8_t head[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
-        memcpy(out, head, 18);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf_.data(), (uInt)buf_.size()), isize = (uint32_t)buf_.size();
-        memcpy(out + 18 + clen, &crc, 4); memcpy(out + 18 + clen + 4, &isize, 4);
-        os_.write((const char *)out, (std::streamsize)bsize);
+        memcpy(out.data(), head, 18);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n), isize = (uint32_t)n;
+        memcpy(out.data() + 18 + clen, &crc, 4); memcpy(out.data() + 18 + clen + 4, &isize, 4);
+        out.resize(bsize);
+    }
+    void flushBlock()
+    {
+        std::vector<uint8_t> out;
+        compressBlock(buf_.data(), buf_.size(), out);
+        os_.write((const char *)out.data(), (std::streamsize)out.size());
         buf_.clear();
     }
     std::ostream & os_;
@@ -100,9 +128,12 @@ inline void bamWriteHeader(BgzfWriter & w, const std::string & text, const std::
     }
 }
 
-inline void bamWriteRecord(BgzfWriter & w, const AlnRecord & r, std::vector<uint8_t> & scratch)
+// appends block_size + the record to `out`
+inline void bamEncodeRecord(const AlnRecord & r, std::vector<uint8_t> & out)
 {
-    scratch.clear();
+    const size_t sizeAt = out.size();
+    out.resize(sizeAt + 4);
+    std::vector<uint8_t> & scratch = out;
     auto put = [&](const void * p, size_t n) { scratch.insert(scratch.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
     auto put32 = [&](uint32_t v) { put(&v, 4); };
     int64_t refLen = 0;
@@ -129,9 +160,8 @@ inline void bamWriteRecord(BgzfWriter & w, const AlnRecord & r, std::vector<uint
     if (r.hasCounts) { tagInt("NM", r.nm); tagInt("X0", r.x0); tagInt("X1", r.x1); }
     tagStr("RG", r.rg);
     if (!r.xa.empty()) tagStr("XA", r.xa);
-    const uint32_t blockSize = (uint32_t)scratch.size();
-    w.put<uint32_t>(blockSize);
-    w.write(scratch.data(), scratch.size());
+    const uint32_t blockSize = (uint32_t)(out.size() - sizeAt - 4);
+    memcpy(out.data() + sizeAt, &blockSize, 4);
 }
 
 inline void samWriteRecord(std::string & out, const AlnRecord & r, const std::vector<std::string> & names)

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <thread>
 
 using namespace dy;
 
@@ -20,6 +21,7 @@ struct CliOptions
     std::string indicesDir, readsFile, readsFile2, outputFile, filterFile, filterType = "bloom", readGroup = "none";
     dy_params params;
     unsigned readsBatch = 100000;
+    unsigned hostThreads = 0;          // 0 = min(16, hardware threads)
     bool verbose = false, skipSamHeader = false;
     std::string commandLine;
 };
@@ -60,7 +62,7 @@ CliOptions parse(int argc, char ** argv)
         else if (a == "-o" || a == "--output-file") o.outputFile = value();
         else if (a == "-rg" || a == "--read-group") o.readGroup = value();
         else if (a == "-sm" || a == "--secondary-matches") value();      // read under a legacy name by the reference: no effect (:320)
-        else if (a == "-t" || a == "--threads") uintValue(1, 2048);      // the device replaces the thread pool
+        else if (a == "-t" || a == "--threads") o.hostThreads = uintValue(1, 2048);      // the device replaces the mapping threads; these format the output
         else if (a == "-rb" || a == "--reads-batch") o.readsBatch = uintValue(1000, 5000000);
         else if (a == "-sk" || a == "--skip-sam-headers") o.skipSamHeader = true;
         else if (a == "-ll" || a == "--library-length") o.params.library_length = uintValue(1, 1000000000u);      // src/d_mapper.cpp:209-216
@@ -126,7 +128,7 @@ int main(int argc, char ** argv)
             for (size_t c = 0; c < contigNames.size(); ++c) headerText += "@SQ\tSN:" + contigNames[c] + "\tLN:" + std::to_string(contigLengths[c]) + "\n";
         }
         BgzfWriter bgzf(os);
-        std::vector<uint8_t> bamScratch;
+        const unsigned hostThreads = opt.hostThreads ? opt.hostThreads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         if (bam) bamWriteHeader(bgzf, headerText, contigNames, contigLengths);
         else os << headerText;
 
@@ -170,7 +172,12 @@ int main(int argc, char ** argv)
             const dy_match * ms = dy_result_matches(res);
             const uint32_t * cg = dy_result_cigars(res);
             // ---- alignment records (reference src/mapper_writer.h:296-345, 593-634; pairs :268-293,347-400,515-571)
-            for (size_t i = 0; i < batch.size(); ++i)
+            const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(hostThreads, batch.size() / 4096 + 1));
+            std::vector<std::string> samChunk(T); std::vector<std::vector<uint8_t>> bamChunk(T); std::vector<unsigned long long> mappedChunk(T, 0);
+            auto formatChunk = [&](unsigned c) {
+            std::string recText;
+            const size_t lo = batch.size() * c / T, hi = batch.size() * (c + 1) / T;
+            for (size_t i = lo; i < hi; ++i)
             {
                 const dy_read_result & r = rr[i];
                 AlnRecord a;
@@ -226,9 +233,22 @@ int main(int argc, char ** argv)
                         appendUint(a.xa, m.errors); a.xa += ';';
                     }
                 }
-                if (bam) bamWriteRecord(bgzf, a, bamScratch);
-                else { rec.clear(); samWriteRecord(rec, a, contigNames); os << rec; }
-                mapped += r.mapped;
+                if (bam) bamEncodeRecord(a, bamChunk[c]);
+                else samWriteRecord(samChunk[c], a, contigNames);
+                mappedChunk[c] += r.mapped;
+            }
+            };
+            {
+                std::vector<std::thread> pool;
+                for (unsigned c = 1; c < T; ++c) pool.emplace_back(formatChunk, c);
+                formatChunk(0);
+                for (auto & th : pool) th.join();
+            }
+            for (unsigned c = 0; c < T; ++c)
+            {
+                if (bam) bgzf.writeParallel(bamChunk[c].data(), bamChunk[c].size(), hostThreads);
+                else os.write(samChunk[c].data(), (std::streamsize)samChunk[c].size());
+                mapped += mappedChunk[c];
             }
             total += batch.size();
             dy_result_free(res);

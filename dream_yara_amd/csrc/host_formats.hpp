@@ -6,6 +6,7 @@
 #include "dy_types.h"
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <stdexcept>
 #include <cstdio>
 #include <cstring>
@@ -229,33 +230,45 @@ public:
         else if (map_.size() >= 3 && map_.data()[0] == 'B' && map_.data()[1] == 'Z' && map_.data()[2] == 'h')
             throw IoError("bzip2-compressed input is not supported (no libbz2 on this system)");
     }
-    // appends up to maxReads records; returns the number appended
+    // appends up to maxReads records; returns the number appended.  Works on byte spans of the mapped file (no temporaries):
+    // one memchr per line, a 256-entry table for the bases.
     size_t next(ReadsBatch & b, size_t maxReads)
     {
+        static const Dna5Table lut;
         b.clear();
         size_t n = 0;
         while (n < maxReads)
         {
             skipBlank();
             if (p_ >= end_) break;
-            char marker = (char)*p_;
+            const char marker = (char)*p_;
             if (marker != '>' && marker != '@') throw IoError("unrecognised reads file format");
-            std::string header = line();
-            b.names.push_back(header.substr(1));
-            size_t start = b.codes.size();
+            const u8 * s, * e;
+            span(s, e);
+            b.names.emplace_back((const char *)s + 1, (const char *)e);
+            const size_t start = b.codes.size();
             if (marker == '>')
             {
-                while (p_ < end_ && *p_ != '>') { std::string s = line(); for (char c : s) b.codes.push_back(dna5Code(c)); }
+                while (p_ < end_ && *p_ != '>')
+                {
+                    span(s, e);
+                    const size_t at = b.codes.size();
+                    b.codes.resize(at + (size_t)(e - s));
+                    for (size_t i = 0; i < (size_t)(e - s); ++i) b.codes[at + i] = lut.code[s[i]];
+                }
                 b.quals.resize(b.codes.size(), 'I');
             }
             else
             {
-                std::string s = line(); for (char c : s) b.codes.push_back(dna5Code(c));
-                line();                                   // '+'
-                std::string q = line();
-                b.quals.resize(b.codes.size(), 'I');
-                for (size_t i = 0; i < q.size() && start + i < b.codes.size(); ++i)
-                    b.quals[start + i] = (char)(q[i] > 33 + 62 ? 33 + 62 : q[i]);   // Dna5Q keeps 6 quality bits
+                span(s, e);
+                const size_t len = (size_t)(e - s);
+                b.codes.resize(start + len);
+                for (size_t i = 0; i < len; ++i) b.codes[start + i] = lut.code[s[i]];
+                span(s, e);                               // '+'
+                span(s, e);
+                b.quals.resize(start + len, 'I');
+                const size_t ql = std::min(len, (size_t)(e - s));
+                for (size_t i = 0; i < ql; ++i) b.quals[start + i] = (char)(s[i] > 33 + 62 ? 33 + 62 : s[i]);   // Dna5Q keeps 6 quality bits
             }
             for (size_t i = start; i < b.codes.size(); ++i) if (b.codes[i] == 4) b.quals[i] = '!';   // N carries no quality
             b.offs.push_back(b.codes.size());
@@ -264,15 +277,16 @@ public:
         return n;
     }
 private:
+    struct Dna5Table { u8 code[256]; Dna5Table() { for (int c = 0; c < 256; ++c) code[c] = dna5Code((char)c); } };
     void skipBlank() { while (p_ < end_ && (*p_ == '\n' || *p_ == '\r')) ++p_; }
-    std::string line()
+    // [s, e) = the next line without its terminator and trailing CR / blanks
+    void span(const u8 *& s, const u8 *& e)
     {
-        const u8 * s = p_;
-        while (p_ < end_ && *p_ != '\n') ++p_;
-        const u8 * e = p_;
-        if (p_ < end_) ++p_;
+        s = p_;
+        const u8 * nl = (const u8 *)memchr(p_, '\n', (size_t)(end_ - p_));
+        e = nl ? nl : end_;
+        p_ = nl ? nl + 1 : end_;
         while (e > s && (e[-1] == '\r' || e[-1] == ' ')) --e;
-        return std::string((const char *)s, (const char *)e);
     }
     MappedFile map_;
     std::vector<u8> inflated_;
