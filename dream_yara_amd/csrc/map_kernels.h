@@ -420,8 +420,17 @@ __device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 *
             u32 minErr = remaining + 1;
             int endPos = 0;
             const u32 hb = hayBegin - 1 - lcp, nb = needleBegin - 1 - lcp;
-            myersPrefixSearch<NW>([&](int i) { return (u32)seq[nb - i]; }, ndlLen - lcp,
-                                  [&](int j) { return (u32)ctg[hb - j]; }, hayLen - lcp, (int)remaining,
+            // the Myers loops ask for elements 0, 1, 2, ... with a wave-uniform index: one 8-byte load serves eight of them (a
+            // byte load per column costs the texture addresser a full divergent access each time); elements whose 8-byte group
+            // would start before the array are fetched singly
+            u64 nw = 0, tw = 0;
+            auto needleAt = [&](int i) -> u32 {
+                if ((i & 7) == 0) { if (nb >= (u32)i + 7) nw = load8(seq + nb - i - 7); else { nw = 0; for (u32 t = 0; t < 8 && (u32)i + t <= nb; ++t) nw |= (u64)seq[nb - i - t] << (8 * (7 - t)); } }
+                return (u32)(nw >> (8 * (7 - (i & 7)))) & 0xff; };
+            auto textAt = [&](int j) -> u32 {
+                if ((j & 7) == 0) { if (hb >= (u32)j + 7) tw = load8(ctg + hb - j - 7); else { tw = 0; for (u32 t = 0; t < 8 && (u32)j + t <= hb; ++t) tw |= (u64)ctg[hb - j - t] << (8 * (7 - t)); } }
+                return (u32)(tw >> (8 * (7 - (j & 7)))) & 0xff; };
+            myersPrefixSearch<NW>(needleAt, ndlLen - lcp, textAt, hayLen - lcp, (int)remaining,
                                   [&](int pos, int dist) { if ((u32)dist <= minErr) { minErr = (u32)dist; endPos = pos + 1; } });
             errors += minErr;
             matchBegin -= (u32)(endPos + lcp);
@@ -453,8 +462,10 @@ __device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 *
             const u32 hb = hayEnd + lcp, nb = needleEnd + lcp;
             const int hl = hayLen - lcp, nl = ndlLen - lcp;
             const u32 lastNeedle = seq[nb + nl - 1];
-            myersPrefixSearch<NW>([&](int i) { return (u32)seq[nb + i]; }, nl - 1,
-                                  [&](int j) { return (u32)ctg[hb + j]; }, hl - 1, (int)remaining,
+            u64 nw = 0, tw = 0;        // forward: an 8-byte load may run past the needle / window, never past the padded arrays
+            auto needleAt = [&](int i) -> u32 { if ((i & 7) == 0) nw = load8(seq + nb + i); return (u32)(nw >> (8 * (i & 7))) & 0xff; };
+            auto textAt = [&](int j) -> u32 { if ((j & 7) == 0) tw = load8(ctg + hb + j); return (u32)(tw >> (8 * (j & 7))) & 0xff; };
+            myersPrefixSearch<NW>(needleAt, nl - 1, textAt, hl - 1, (int)remaining,
                                   [&](int pos, int dist) {
                                       const int currentEnd = pos + 1;
                                       u32 cur = (u32)dist;
