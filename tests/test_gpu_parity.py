@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLD_INDEX, GENOMES_FA, READS_FA, GOLDEN, read_fasta_codes, sam_records
+from conftest import bam_to_sam_lines, GOLD_INDEX, GENOMES_FA, READS_FA, GOLDEN, read_fasta_codes, sam_records
 
 pytestmark = pytest.mark.gpu
 
@@ -426,66 +426,6 @@ def _write_fastq(path, codes, offs, lo, hi, suffix):
             f.write("@pair%d%s\n%s\n+\n%s\n" % (i - lo, suffix, seq, "I" * len(seq)))
 
 
-def _bam_to_sam_lines(path):
-    """Minimal BAM decoder (spec v1) for the test: returns (header text, reference names, SAM-formatted record lines)."""
-    import gzip, struct
-    raw = open(path, "rb").read()
-    # BGZF structure: every member carries the BC extra field and the file ends with the 28-byte EOF block
-    assert raw[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
-    off, n_blocks = 0, 0
-    while off < len(raw):
-        assert raw[off:off + 4] == b"\x1f\x8b\x08\x04" and raw[off + 12:off + 14] == b"BC"
-        off += struct.unpack_from("<H", raw, off + 16)[0] + 1
-        n_blocks += 1
-    assert off == len(raw)
-    data = gzip.decompress(raw)
-    assert data[:4] == b"BAM\x01"
-    l_text, = struct.unpack_from("<i", data, 4)
-    text = data[8:8 + l_text].decode()
-    p = 8 + l_text
-    n_ref, = struct.unpack_from("<i", data, p); p += 4
-    refs = []
-    for _ in range(n_ref):
-        l_name, = struct.unpack_from("<i", data, p); p += 4
-        name = data[p:p + l_name - 1].decode(); p += l_name
-        l_ref, = struct.unpack_from("<i", data, p); p += 4
-        refs.append((name, l_ref))
-    lines = []
-    while p < len(data):
-        bs, = struct.unpack_from("<i", data, p); p += 4
-        rid, pos, l_rn, mapq, bin_, n_cig, flag, l_seq, nrid, npos, tlen = struct.unpack_from("<iiBBHHHiiii", data, p)
-        q = p + 32
-        qname = data[q:q + l_rn - 1].decode(); q += l_rn
-        cig = struct.unpack_from("<%dI" % n_cig, data, q); q += 4 * n_cig
-        seqb = data[q:q + (l_seq + 1) // 2]; q += (l_seq + 1) // 2
-        seq = "".join("=ACMGRSVTWYHKDBN"[(seqb[i // 2] >> (4 if i % 2 == 0 else 0)) & 15] for i in range(l_seq))
-        qual = "".join(chr(c + 33) for c in data[q:q + l_seq]); q += l_seq
-        tags = []
-        end = p + bs
-        while q < end:
-            tag, typ = data[q:q + 2].decode(), chr(data[q + 2]); q += 3
-            if typ == "i":
-                tags.append("%s:i:%d" % (tag, struct.unpack_from("<i", data, q)[0])); q += 4
-            else:
-                assert typ == "Z"
-                z = data.index(b"\0", q); tags.append("%s:Z:%s" % (tag, data[q:z].decode())); q = z + 1
-        assert q == end
-        ref_len = sum(c >> 4 for c in cig if (c & 15) != 1)
-        beg, e = pos, (pos + ref_len if ref_len else pos + 1) if pos >= 0 else 0
-        def reg2bin(b, e):
-            e -= 1
-            for sh, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
-                if b >> sh == e >> sh: return base + (b >> sh)
-            return 0
-        assert bin_ == reg2bin(beg, e) & 0xffff
-        cigar = "".join("%d%s" % (c >> 4, "MID"[c & 15]) for c in cig) or "*"
-        rname = refs[rid][0] if rid >= 0 else "*"
-        rnext = "*" if nrid < 0 else ("=" if nrid == rid else refs[nrid][0])
-        lines.append("\t".join([qname, str(flag), rname, str(pos + 1), str(mapq), cigar, rnext, str(npos + 1), str(tlen), seq, qual] + tags))
-        p = end
-    return text, refs, lines, n_blocks
-
-
 def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
     """-o x.bam gives a valid BGZF/BAM whose decoded records equal the SAM run; gzip-compressed reads give the same output."""
     import gzip, shutil
@@ -499,7 +439,7 @@ def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
     subprocess.check_call(base + [READS_FA, "-o", bam])
     subprocess.check_call(base + [gz_reads, "-o", sam_gz])
     sam_lines = [l.rstrip("\n") for l in open(sam)]
-    text, refs, recs, n_blocks = _bam_to_sam_lines(bam)
+    text, refs, recs, n_blocks = bam_to_sam_lines(bam)
     hdr = [l for l in sam_lines if l.startswith("@")]
     assert [l for l in text.splitlines() if not l.startswith("@PG")] == [l for l in hdr if not l.startswith("@PG")]
     assert [("@SQ\tSN:%s\tLN:%d" % r) for r in refs] == [l for l in hdr if l.startswith("@SQ")]

@@ -1,0 +1,53 @@
+"""Host-side I/O of dream_yara_mapper without a GPU: the FASTA/FASTQ/gzip parser and the SAM / BGZF-BAM writers
+(dream_yara_amd/csrc/host_formats.hpp, bam_writer.hpp) through a small harness compiled here with g++."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT, bam_to_sam_lines
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("hostio") / "host_io_harness")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-DDY_HAVE_ZLIB", "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "host_io_harness.cpp"), "-lz"])
+    return exe
+
+
+def test_reads_parser_handles_fasta_fastq_gzip_and_odd_lines(harness, tmp_path):
+    fq = tmp_path / "a.fq"
+    fq.write_bytes(b"@r1 first read/1\nACGTNacgtn\n+\nIIII!IIII~\n"
+                   b"@r2\r\nTTTT\r\n+r2\r\n@@@@\r\n"          # CRLF, quality line that starts with '@'
+                   b"\n@r3\nA\n+\nI\n")                        # blank line between records, 1-base read
+    out = subprocess.check_output([harness, "parse", str(fq), "2"], stderr=subprocess.PIPE).decode().splitlines()
+    assert out == ["r1 first read/1\tACGTNACGTN\tIIII!IIII!",      # N carries no quality ('!'); '~' is clamped to 6 bits but N wins here
+                   "r2\tTTTT\t@@@@",
+                   "r3\tA\tI"]
+    fa = tmp_path / "b.fa"
+    fa.write_bytes(b">s1 desc\nACGT\nNNAC\n\n>s2\nGGGGGGGGGG\n>s3\nRYKM\n")       # wrapped FASTA, IUPAC codes -> N
+    out = subprocess.check_output([harness, "parse", str(fa), "100"]).decode().splitlines()
+    assert out == ["s1 desc\tACGTNNAC\tIIII!!II", "s2\tGGGGGGGGGG\tIIIIIIIIII", "s3\tNNNN\t!!!!"]
+    gz = tmp_path / "a.fq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(fq.read_bytes())
+    assert subprocess.check_output([harness, "parse", str(gz), "1"]) == subprocess.check_output([harness, "parse", str(fq), "1000"])
+    bad = tmp_path / "bad.txt"
+    bad.write_text("hello\n")
+    assert subprocess.call([harness, "parse", str(bad), "10"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
+
+
+@pytest.mark.parametrize("n,threads", [(0, 1), (50, 1), (4000, 4)])
+def test_bam_stream_decodes_to_the_sam_text(harness, tmp_path, n, threads):
+    sam, bam = str(tmp_path / "o.sam"), str(tmp_path / "o.bam")
+    subprocess.check_call([harness, "write", sam, bam, str(n), str(threads)])
+    lines = [l.rstrip("\n") for l in open(sam)]
+    text, refs, recs, n_blocks = bam_to_sam_lines(bam)        # also checks the BGZF framing, the EOF block and the bin field
+    assert text.splitlines() == [l for l in lines if l.startswith("@")]
+    assert [r[0] for r in refs] == ["chrA", "chrB", "a_rather_long_contig_name.1"]
+    assert recs == [l for l in lines if not l.startswith("@")]
+    assert len(recs) == n
+    if n == 4000:
+        assert n_blocks > 5                                    # several blocks, deflated by the worker threads
