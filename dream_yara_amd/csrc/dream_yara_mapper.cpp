@@ -11,6 +11,7 @@
 #include <chrono>
 #include <memory>
 #include <thread>
+#include <future>
 
 using namespace dy;
 
@@ -136,12 +137,14 @@ int main(int argc, char ** argv)
         std::unique_ptr<ReadsFile> in2;
         if (opt.params.paired) in2.reset(new ReadsFile(opt.readsFile2));
         if (opt.params.paired && opt.readsBatch > 1048575) opt.readsBatch = 1048575;      // both mates share the 21-bit read id space
-        ReadsBatch batch;
+        // Three batches are in flight: one being parsed, one on the device, one being formatted and written (in input order).
+        struct Slot { ReadsBatch batch; dy_reads * reads = nullptr; dy_result * res = nullptr; size_t nPairs = 0; };
+        Slot slots[3];
         unsigned long long total = 0, mapped = 0;
         double mapSeconds = 0;
-        std::string rec;
-        while (in.next(batch, opt.readsBatch))
-        {
+        auto readInto = [&](Slot & sl) -> bool {
+            ReadsBatch & batch = sl.batch;
+            if (!in.next(batch, opt.readsBatch)) return false;
             if (in2)
             {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
                 ReadsBatch second;
@@ -152,25 +155,15 @@ int main(int argc, char ** argv)
                 batch.quals.insert(batch.quals.end(), second.quals.begin(), second.quals.end());
                 for (size_t i = 1; i < second.offs.size(); ++i) batch.offs.push_back(second.offs[i] + shift);
             }
-            const size_t nPairs = batch.size() / 2;
-            auto m0 = std::chrono::steady_clock::now();
-            dy_reads * reads = nullptr;
-            check(dy_reads_upload(ctx, batch.codes.data(), batch.offs.data(), (uint32_t)batch.size(), &reads));
-            if (ibf)
-            {
-                // threshold from the batch-average read length (reference src/d_mapper.h:313-315)
-                uint16_t avg = (uint16_t)(batch.offs.back() * 2 / (batch.size() * 2));
-                dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
-                uint16_t thr = dy_ibf_threshold(opt.params.error_rate, info.kmer_size, avg);
-                if (thr == 0) std::cerr << "[WARNING!] 0 k-mer is required to filter a read!\nAll reads will pass filteration and be mapped everywhere.\n";
-                check(dy_ibf_query(ibf, reads, thr, nullptr));
-            }
-            dy_result * res = nullptr;
-            check(dy_map_reads(ctx, idx, reads, &opt.params, &res));
-            mapSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
-            const dy_read_result * rr = dy_result_reads(res);
-            const dy_match * ms = dy_result_matches(res);
-            const uint32_t * cg = dy_result_cigars(res);
+            sl.nPairs = batch.size() / 2;
+            return true;
+        };
+        auto formatAndWrite = [&](Slot & sl) {
+            const ReadsBatch & batch = sl.batch;
+            const size_t nPairs = sl.nPairs;
+            const dy_read_result * rr = dy_result_reads(sl.res);
+            const dy_match * ms = dy_result_matches(sl.res);
+            const uint32_t * cg = dy_result_cigars(sl.res);
             // ---- alignment records (reference src/mapper_writer.h:296-345, 593-634; pairs :268-293,347-400,515-571)
             const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(hostThreads, batch.size() / 4096 + 1));
             std::vector<std::string> samChunk(T); std::vector<std::vector<uint8_t>> bamChunk(T); std::vector<unsigned long long> mappedChunk(T, 0);
@@ -251,9 +244,42 @@ int main(int argc, char ** argv)
                 mapped += mappedChunk[c];
             }
             total += batch.size();
-            dy_result_free(res);
-            dy_reads_free(reads);
+        };
+        auto release = [&](Slot & sl) {          // device objects go back on the thread that drives the context
+            if (sl.res) { dy_result_free(sl.res); sl.res = nullptr; }
+            if (sl.reads) { dy_reads_free(sl.reads); sl.reads = nullptr; }
+        };
+        std::future<void> writer;                // at most one: keeps the output in input order
+        int writing = -1;
+        int cur = 0;
+        bool have = readInto(slots[cur]);
+        while (have)
+        {
+            Slot & sl = slots[cur];
+            const int nxt = (cur + 1) % 3;
+            if (writing == nxt) { writer.get(); release(slots[nxt]); writing = -1; }      // the slot about to be refilled must be written out
+            std::future<bool> reader = std::async(std::launch::async, [&, nxt] { return readInto(slots[nxt]); });
+            const ReadsBatch & batch = sl.batch;
+            auto m0 = std::chrono::steady_clock::now();
+            check(dy_reads_upload(ctx, batch.codes.data(), batch.offs.data(), (uint32_t)batch.size(), &sl.reads));
+            if (ibf)
+            {
+                // threshold from the batch-average read length (reference src/d_mapper.h:313-315)
+                uint16_t avg = (uint16_t)(batch.offs.back() * 2 / (batch.size() * 2));
+                dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
+                uint16_t thr = dy_ibf_threshold(opt.params.error_rate, info.kmer_size, avg);
+                if (thr == 0) std::cerr << "[WARNING!] 0 k-mer is required to filter a read!\nAll reads will pass filteration and be mapped everywhere.\n";
+                check(dy_ibf_query(ibf, sl.reads, thr, nullptr));
+            }
+            check(dy_map_reads(ctx, idx, sl.reads, &opt.params, &sl.res));
+            mapSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
+            if (writing >= 0) { writer.get(); release(slots[writing]); writing = -1; }
+            writer = std::async(std::launch::async, [&, cur] { formatAndWrite(slots[cur]); });
+            writing = cur;
+            have = reader.get();
+            cur = nxt;
         }
+        if (writing >= 0) { writer.get(); release(slots[writing]); }
         if (bam) bgzf.finish();
         os.flush();
         if (opt.verbose)

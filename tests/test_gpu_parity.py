@@ -196,7 +196,8 @@ def test_map_without_the_device_only_tables(dy, ctx, ob, small_filter, monkeypat
     oidx.close(); oibf.close()
 
 
-@pytest.mark.parametrize("gold,extra", [("t1", []), ("tag.t1", ["-sm", "tag", "-s", "10"]), ("rec.t1", ["-sm", "record", "-s", "10"])])
+@pytest.mark.parametrize("gold,extra", [("t1", []), ("tag.t1", ["-sm", "tag", "-s", "10"]), ("rec.t1", ["-sm", "record", "-s", "10"]),
+                                        ("t1", ["-rb", "1000", "-t", "3"])])       # 7 batches through the 3-slot reader / device / writer pipeline
 def test_cli_reproduces_gold_sam(product_build, dy, small_filter, tmp_path, gold, extra):
     out = str(tmp_path / "out.sam")
     subprocess.check_call([os.path.join(product_build, "dream_yara_mapper"), "-fi", small_filter, GOLD_INDEX + "/", READS_FA,
