@@ -664,6 +664,69 @@ def test_multi_contig_bins_match_oracle(dy, ctx, ob, tmp_path, use_filter):
     if oibf: oibf.close()
 
 
+# ---------------------------------------------------------------------------------------------- error behaviour of the boundary
+def test_abi_error_codes_and_messages(dy, ctx, small_filter, tmp_path):
+    """Errors come back as DY_E* codes with the reference's wording where it has one (reference src/mapper.h:453-454,
+    src/d_mapper.cpp:574-582); nothing crashes, nothing falls back."""
+    EINVAL, EIO, EUNSUPPORTED = -1, -2, -6
+    codes = np.zeros(300, np.uint8); offs = np.array([0, 100, 200, 300], np.uint64)
+    idx = dy.Index(ctx, GOLD_INDEX, 64)
+    reads = dy.Reads(ctx, codes, offs)
+    with pytest.raises(dy.DyError) as e:                      # masks missing: the filter has to run first
+        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03)))
+    assert e.value.code == EINVAL and "dy_ibf_query" in str(e.value)
+    ibf = dy.Ibf.load(ctx, small_filter)
+    ibf.query(reads, 10, want_masks=False)
+    with pytest.raises(dy.DyError) as e:                      # odd number of reads in a paired batch
+        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03), paired=1))
+    assert e.value.code == EINVAL
+    with pytest.raises(dy.DyError) as e:                      # -y full
+        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03), sensitivity=2))
+    assert e.value.code == EUNSUPPORTED and "full" in str(e.value)
+    with pytest.raises(dy.DyError) as e:
+        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.5)))
+    assert e.value.code == EINVAL
+    with pytest.raises(dy.DyError) as e:                      # reference: "Maximum read length exceeded."
+        dy.Reads(ctx, np.zeros(9000, np.uint8), np.array([0, 9000], np.uint64))
+    assert e.value.code == EINVAL and "Maximum read length exceeded" in str(e.value)
+    with pytest.raises(dy.DyError) as e:
+        dy.Index(ctx, str(tmp_path / "nowhere"), 4)
+    assert e.value.code == EIO
+    bad = tmp_path / "bad.filter"; bad.write_bytes(b"\x00" * 20)
+    with pytest.raises(dy.DyError) as e:
+        dy.Ibf.load(ctx, str(bad))
+    assert e.value.code in (EIO, EINVAL)
+    with pytest.raises(dy.DyError) as e:                      # a filter of another bin count than the index
+        f2 = dy.Ibf.create(ctx, 32, 2, 12, (1 << 20) + 256)
+        f2.query(reads, 5, want_masks=False)
+        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03)))
+    assert e.value.code == EINVAL
+    # after all those refusals the handles still work
+    ibf.query(reads, 10, want_masks=False)
+    res = dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03)))
+    assert res.reads().size == 3
+    res.close(); f2.close(); ibf.close(); reads.close(); idx.close()
+
+
+def test_cli_errors_exit_1_with_the_tool_name(product_build, small_filter, tmp_path):
+    exe = os.path.join(product_build, "dream_yara_mapper")
+    def run(args):
+        p = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        return p.returncode, p.stderr.decode()
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", str(tmp_path / "missing.fa")])
+    assert rc == 1 and err.startswith("dream_yara_mapper: ")
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "--no-such-option"])
+    assert rc == 1 and "unknown option" in err
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-e", "11"])
+    assert rc == 1 and "out of range" in err
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-y", "full"])
+    assert rc == 1 and "not implemented" in err
+    rc, err = run(["-fi", str(tmp_path / "none.filter"), GOLD_INDEX + "/", READS_FA])
+    assert rc == 1 and err.startswith("dream_yara_mapper: ")
+    rc, err = run([GOLD_INDEX + "/"])
+    assert rc == 1
+
+
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
 @pytest.mark.parametrize("strata", [0.0, 0.02])
 def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata):
