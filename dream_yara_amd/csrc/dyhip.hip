@@ -791,19 +791,19 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
                 // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
                 const u32 ldsBudget = getenv("DY_IBF_LDS_KB") ? (u32)atoi(getenv("DY_IBF_LDS_KB")) * 1024 : 12 * 1024;
-                const u32 cacheKmers = ldsBudget > hashSlots * 8 ? std::min<u32>(nK, (u32)((ldsBudget - hashSlots * 8) / (G * 8))) : 0;
-                const size_t perWave = (hashSlots + (size_t)cacheKmers * G) * 8;
+                // sparse verification pays when false candidates are expected in numbers, i.e. at thresholds far below the k-mer count
+                const u32 sparseCap = (nK < 256 && nK <= hashSlots && 4u * threshold <= nK && !getenv("DY_IBF_DENSE")) ? 1024 : 0;
+                const u32 fixedWords = hashSlots + (sparseCap ? 16 + 128 + sparseCap / 4 : 0);
+                const u32 cacheKmers = ldsBudget > fixedWords * 8 ? std::min<u32>(nK, (u32)((ldsBudget - fixedWords * 8) / (G * 8))) : 0;
+                const size_t perWave = ((size_t)fixedWords + (size_t)cacheKmers * G) * 8;
                 const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-                if (nK <= 127)
-                    hipLaunchKernelGGL(k_ibf_query_wide<7>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
-                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots);
-                else if (nK <= 255)
-                    hipLaunchKernelGGL(k_ibf_query_wide<8>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
-                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots);
-                else
-                    hipLaunchKernelGGL(k_ibf_query_wide<14>, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(),
-                                       reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots);
+#define DY_LAUNCH_WIDE(NPV, SP) hipLaunchKernelGGL((k_ibf_query_wide<NPV, SP>), grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, \
+                                   reads->seqs.as<u8>(), reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots, sparseCap)
+                if (nK <= 127) { if (sparseCap) DY_LAUNCH_WIDE(7, true); else DY_LAUNCH_WIDE(7, false); }
+                else if (nK <= 255) { if (sparseCap) DY_LAUNCH_WIDE(8, true); else DY_LAUNCH_WIDE(8, false); }
+                else DY_LAUNCH_WIDE(14, false);
+#undef DY_LAUNCH_WIDE
             }
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));

@@ -326,10 +326,10 @@ __device__ __forceinline__ void planesReduceSlots(u64 (&planes)[NP], u32 G, u32 
     }
 }
 
-template <int NP>
+template <int NP, bool SPARSE>
 __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__ words, IbfGeom g,
                                                         const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
-                                                        u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 cacheKmers, u32 hashSlots)
+                                                        u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 cacheKmers, u32 hashSlots, u32 sparseCap)
 {
     extern __shared__ u64 ldsWide[];
     constexpr u32 UA = 8, UB = 4;   // sub-passes whose gathers are in flight together (phase A / phase B)
@@ -354,8 +354,14 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
     const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
     // LDS per wave: the k-mer hashes of one strand (all of them when hashSlots >= nKmers, else a window of hashSlots = 128) and
     // the hash-0 words of the first cacheKmers k-mers
-    u64 * myHash = ldsWide + (size_t)wave * (hashSlots + (size_t)cacheKmers * G);
+    // ... and, when sparseCap != 0, the scratch of the sparse verification: candidate mask per word (16 x u64), byte counters per
+    // (word, bin) (16 x 64 bytes = 128 x u64) and a list of sparseCap 16-bit (k-mer, word) pairs
+    const size_t perWave = hashSlots + (size_t)cacheKmers * G + (sparseCap ? 16 + 128 + sparseCap / 4 : 0);
+    u64 * myHash = ldsWide + (size_t)wave * perWave;
     u64 * myW0 = myHash + hashSlots;
+    u64 * spCand = myW0 + (size_t)cacheKmers * G;
+    u32 * spCount = (u32 *)(spCand + 16);
+    u16 * spList = (u16 *)(spCand + 16 + 128);
     const bool hashAll = hashSlots >= nKmers;
     const u32 CH = hashAll ? ((nKmers + 63) & ~63u) : hashSlots;        // k-mers per outer iteration
     u32 perLaneBits = 1; while ((1u << perLaneBits) <= (nKmers + slots - 1) / slots) ++perLaneBits;   // bits of a lane's own counter
@@ -408,6 +414,60 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
             const bool single = (u32)__popcll(candLanes) == slots && ballot64((cand & (cand - 1)) != 0) == 0;
             // few candidate words: fetch the remaining hash functions together; many (low thresholds): one after the other, lazily
             const bool eager = __popcll(candLanes) <= (int)(2 * slots);
+            // ---- phase B, sparse form for many candidates (low thresholds: dozens of false candidates, each carried by a handful of
+            // k-mers): only 1 in ~6 (k-mer, word) slots holds a candidate bit, so the slots that do are compacted into a list and
+            // verified 64 at a time; exact counts are byte counters in LDS.  Needs all hashes in LDS and counts below 256.
+            if constexpr (SPARSE) if (!single && sparseCap && hashAll && nKmers < 256)
+            {
+                __builtin_amdgcn_wave_barrier();
+                if (slot == 0) spCand[wl] = cand;
+                for (u32 i = lane; i < 256; i += 64) spCount[i] = 0;
+                u32 nPairs = 0;
+                bool overflow = false;
+                for (u32 s0 = 0; s0 * slots < nKmers; ++s0)
+                {
+                    const u32 kk = s0 * slots + slot;
+                    u64 c0 = 0;
+                    if (kk < nKmers && cand != 0)
+                        c0 = (kk < cacheKmers ? myW0[(size_t)kk * G + wl] : words[ibfWordIndex(g, myHash[kk], 0) + w]) & cand;
+                    const u64 act = ballot64(c0 != 0);
+                    if (nPairs + (u32)__popcll(act) > sparseCap) { overflow = true; break; }
+                    if (c0 != 0) spList[nPairs + (u32)__popcll(act & ((1ull << lane) - 1))] = (u16)((kk << 4) | wl);
+                    nPairs += (u32)__popcll(act);
+                }
+                if (!overflow)
+                {
+                    __builtin_amdgcn_wave_barrier();
+                    for (u32 p0 = 0; p0 < nPairs; p0 += 64)
+                    {
+                        const u32 pi = p0 + lane;
+                        if (pi < nPairs)
+                        {
+                            const u32 e = spList[pi], kk = e >> 4, pw = e & 15;
+                            const u64 hk = myHash[kk];
+                            u64 c = (kk < cacheKmers ? myW0[(size_t)kk * G + pw] : words[ibfWordIndex(g, hk, 0) + w0 + pw]) & spCand[pw];
+                            for (u32 hf = 1; hf < g.nHashes && c; ++hf) c &= words[ibfWordIndex(g, hk, hf) + w0 + pw];
+                            while (c)
+                            {
+                                const u32 b = (u32)__ffsll((long long)c) - 1;
+                                c &= c - 1;
+                                atomicAdd(&spCount[(pw * 64 + b) >> 2], 1u << (8 * (b & 3)));
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    u64 rest = cand, acc = 0;
+                    while (rest)
+                    {
+                        const u32 b = (u32)__ffsll((long long)rest) - 1;
+                        rest &= rest - 1;
+                        if (((spCount[(wl * 64 + b) >> 2] >> (8 * (b & 3))) & 0xffu) >= threshold) acc |= 1ull << b;
+                    }
+                    selW |= acc;
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+            }
             // ---- phase B
 #pragma unroll
             for (int p = 0; p < NP; ++p) planes[p] = 0;

@@ -118,6 +118,35 @@ def test_ibf_edge_cases(dy, ctx, ob, tmp_path, bins, hashes, k, bits):
     dreads.close(); ibf.close(); oibf.close()
 
 
+@pytest.mark.parametrize("bins,bits,k", [(1024, 1 << 27, 12), (192, 1 << 24, 11), (256, 1 << 21, 10)])
+def test_ibf_low_thresholds_many_false_candidates(dy, ctx, ob, tmp_path, bins, bits, k):
+    """More than 64 bins, reads under 256 k-mers and thresholds far below the k-mer count: the regime of the sparse verification
+    in k_ibf_query_wide (dozens of false candidate bins per read; the smallest filter overflows the pair list and takes the
+    dense sweep).  Masks equal the oracle's for every threshold."""
+    rng = np.random.default_rng(bins + k)
+    genomes = [rng.integers(0, 4, 20000, dtype=np.uint8) for _ in range(bins)]
+    goffs = np.arange(bins + 1, dtype=np.uint64) * np.uint64(20000)
+    path = str(tmp_path / "f.filter")
+    ob.build_filter(path, bins, 3, k, bits, np.concatenate(genomes), goffs)
+    reads = []
+    for i in range(600):
+        b = int(rng.integers(0, bins)); L = int(rng.integers(60, 200)); s = int(rng.integers(0, 20000 - L))
+        r = genomes[b][s:s + L].copy()
+        for _ in range(int(rng.integers(0, 6))): r[int(rng.integers(0, L))] = rng.integers(0, 4)
+        if i % 9 == 0: r[int(rng.integers(0, L))] = 4
+        if i % 2: r = np.where(r[::-1] < 4, 3 - r[::-1], 4).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    ibf = dy.Ibf.load(ctx, path); oibf = ob.OracleIbf(path); rd = dy.Reads(ctx, codes, offs)
+    sel = []
+    for thr in (1, 3, 7, 15, 40):
+        m = ibf.query(rd, thr)
+        assert np.array_equal(m, oibf.query(codes, offs, thr)), thr
+        sel.append(float(np.unpackbits(m.view(np.uint8)).sum()) / len(reads))
+    assert sel[0] >= sel[-1] and sel[0] > 2      # low thresholds select (many) more bins than the reads' own; the smallest filter is saturated
+    rd.close(); ibf.close(); oibf.close()
+
+
 def test_ibf_beyond_4gib_matches_oracle(dy, ctx, ob, tmp_path):
     """256 bins (W = 4) over a 5 GiB filter: word indices no longer fit 32 bits.  Filter built on the device, saved in
     the reference's file format, re-read by the oracle; masks must agree for reads sampled from the bins."""
