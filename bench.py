@@ -81,10 +81,16 @@ def cpu_baseline(wl, idx_dir, filter_path, codes, offs, error_rate, sample_reads
     t0 = time.time()
     reads, _, _, _ = ob.map_batch(oidx, oibf, sub_codes, sub_offs, error_rate, threads=threads)
     dt = time.time() - t0
+    # the same restatement on ONE thread, on a smaller slice of the same batch (SURVEY.md §8d asks for both figures)
+    n1 = min(n, 200000)
+    t1 = time.time()
+    ob.map_batch(oidx, oibf, codes[: int(offs[n1])], offs[: n1 + 1], error_rate, threads=1)
+    dt1 = time.time() - t1
     oidx.close(); oibf.close()
     return {"value": n / dt, "unit": "reads/s", "cores": threads, "kind": "port",
             "sample": "%d reads of the same batch, oracle (oracle/dyo_*.hpp) with %d threads, %.1f s; filter/index load excluded" % (n, threads, dt),
-            "mapped_fraction": float(reads["mapped"].mean())}, reads
+            "mapped_fraction": float(reads["mapped"].mean()),
+            "single_thread": {"value": n1 / dt1, "unit": "reads/s", "cores": 1, "sample": "%d reads, %.1f s" % (n1, dt1)}}, reads
 
 
 def main():
