@@ -775,7 +775,11 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
             {
                 const u32 wavesPerBlock = 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-                if (!longReads)
+                const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
+                if (W == 1 && nKmax > 64 && nKmax <= 127 && !getenv("DY_IBF_FULL_TAIL"))
+                    hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                       reads->n, (u32)threshold, reads->masks.as<u64>());
+                else if (!longReads)
                     hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
                 else

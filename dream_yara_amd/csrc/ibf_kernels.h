@@ -257,6 +257,108 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
     }
 }
 
+// K1 for the headline shape: 64 bins or fewer (W = 1) and 65..127 k-mers per read (reads of 82..144 bases at k = 18).  Same
+// answers as k_ibf_query<7>; the second chunk of k-mers is fetched only as far as the decision needs it.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ibf_query_two(const u64 * __restrict__ words, IbfGeom g,
+                                                       const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
+                                                       u32 threshold, u64 * __restrict__ masks)
+{
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (read >= nReads) return;
+    const u8 * seq = seqs + offs[read];
+    const u32 len = (u32)(offs[read + 1] - offs[read]);
+    const u32 k = g.kmerSize;
+    const u64 binMask = g.nBins >= 64 ? ~0ull : ((1ull << g.nBins) - 1);
+    if (len < k || threshold == 0)
+    {
+        if (lane == 0) masks[read] = threshold == 0 ? binMask : 0ull;
+        return;
+    }
+    const u32 nKmers = len - k + 1;             // at most 127, checked by the host for the whole batch
+    const u64 kMask = (1ull << k) - 1;
+    u64 selW = 0;
+    for (u32 strand = 0; strand < 2; ++strand)
+    {
+        const bool firstIsN = strandCode(seq, len, 0, strand) > 3;
+            {   // ---- two chunks (65..127 k-mers), the headline shape: the second chunk (the "tail") is fetched only as far as needed.
+        // After the first 64 k-mers a bin is STRONG (count >= threshold: its verification below can succeed on those k-mers
+        // alone), WEAK (it needs tail hits to reach the threshold) or dead.  Weak bins are false candidates almost always;
+        // the tail is gathered 8 k-mers at a time until they are all dead (bound = hits so far + k-mers not yet fetched).
+        const u32 n0 = min(nKmers, 64u), tail = nKmers - n0;      // shorter reads of the batch simply have no tail
+        const u64 hashA = laneKmerHash(seq, len, strand, 0, lane, k, kMask, firstIsN);
+        const u64 m0 = lane < n0 ? words[ibfWordIndex(g, hashA, 0)] : 0;
+        u64 c0p[7];
+        waveBitSlicedSum(m0, c0p);
+        const u64 alive0 = planesGe(c0p, (int)threshold - (int)tail) & binMask;
+        if (!alive0) continue;
+        const u64 strong = planesGe(c0p, (int)threshold) & binMask;
+        u64 weak = alive0 & ~strong;
+        u64 hashB = 0, m1 = 0;
+        u32 fetched = 0;                                   // tail k-mers gathered so far (lanes [0, fetched))
+        bool haveHashB = false;
+        if (weak)
+        {
+            hashB = laneKmerHash(seq, len, strand, 64, lane, k, kMask, firstIsN); haveHashB = true;
+            while (weak && fetched < tail)
+            {
+                const u32 upTo = min(tail, fetched + 8);
+                if (lane >= fetched && lane < upTo) m1 = words[ibfWordIndex(g, hashB, 0)];
+                fetched = upTo;
+                u64 todo = weak;
+                while (todo)
+                {
+                    const u32 j = (u32)__ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const u32 c1 = (u32)__popcll(ballot64((m1 >> j) & 1));
+                    if (planesGet(c0p, j) + c1 + (tail - fetched) < threshold) weak &= ~(1ull << j);
+                }
+            }
+        }
+        // ---- phase B on strong and surviving weak bins (a surviving weak bin has count0 + count1 >= threshold, tail complete)
+        u64 und = strong | weak;
+        while (und)
+        {
+            const u32 j = __ffsll((long long)und) - 1;
+            und &= und - 1;
+            const u32 c0 = planesGet(c0p, j);
+            u32 exactCnt = 0, seenCnt = 0;
+            bool open = true;
+            for (u32 chunk = 0; chunk < 2 && open; ++chunk)
+            {
+                if (chunk == 1 && fetched < tail)
+                {   // the verification of a strong bin did not reach the threshold on the first 64 k-mers: complete the tail
+                    if (!haveHashB) { hashB = laneKmerHash(seq, len, strand, 64, lane, k, kMask, firstIsN); haveHashB = true; }
+                    if (lane >= fetched && lane < tail) m1 = words[ibfWordIndex(g, hashB, 0)];
+                    fetched = tail;
+                }
+                const u64 hash = chunk ? hashB : hashA;
+                const u64 mw = chunk ? m1 : m0;
+                // upper bound of the whole count: hits among the fetched k-mers + every k-mer not fetched yet
+                const u32 bound0 = c0 + (u32)__popcll(ballot64((m1 >> j) & 1)) + (tail - fetched);
+                u64 pending = ballot64((mw >> j) & 1);
+                while (pending && open)
+                {
+                    const u32 need = threshold - exactCnt;
+                    const bool act = ((pending >> lane) & 1) && (u32)__popcll(pending & ((1ull << lane) - 1)) < need;
+                    bool hit = act;
+                    if (act)
+                        for (u32 hf = 1; hf < g.nHashes; ++hf) hit &= (words[ibfWordIndex(g, hash, hf)] >> j) & 1;
+                    const u64 actMask = ballot64(act);
+                    exactCnt += (u32)__popcll(ballot64(hit));
+                    seenCnt += (u32)__popcll(actMask);
+                    pending &= ~actMask;
+                    if (exactCnt >= threshold) { selW |= 1ull << j; open = false; }
+                    else if (exactCnt + (bound0 - seenCnt) < threshold) open = false;
+                }
+            }
+        }
+        continue;
+    }
+    }
+    if (lane == 0) masks[read] = selW;
+}
+
 // ---- K1 for filters with more than 64 bins (W >= 2 words per hash position) ------------------------------------------
 // A hash position is W consecutive words (32 B at 256 bins, 128 B at 1024 bins), so G = min(pow2 >= W, 16) adjacent lanes
 // serve one k-mer and a sub-pass of the wave covers 64/G k-mers with fully used 32..128-byte requests; every lane keeps

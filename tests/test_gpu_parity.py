@@ -118,6 +118,32 @@ def test_ibf_edge_cases(dy, ctx, ob, tmp_path, bins, hashes, k, bits):
     dreads.close(); ibf.close(); oibf.close()
 
 
+@pytest.mark.parametrize("bins,bits,k", [(64, 1 << 24, 14), (37, 1 << 20, 12), (64, 1 << 18, 10)])
+def test_ibf_adaptive_tail_matches_oracle(dy, ctx, ob, tmp_path, bins, bits, k):
+    """64 bins or fewer and at most 127 k-mers per read: k_ibf_query_two fetches the second chunk of k-mers only as far as the
+    decision needs.  Dense filters (false candidates that survive the first 64 k-mers, some until the very end), mixed read
+    lengths around the 64-k-mer boundary, every threshold from 1 to beyond the k-mer count."""
+    rng = np.random.default_rng(bins * 7 + k)
+    genomes = [rng.integers(0, 4, 30000, dtype=np.uint8) for _ in range(bins)]
+    goffs = np.arange(bins + 1, dtype=np.uint64) * np.uint64(30000)
+    path = str(tmp_path / "f.filter")
+    ob.build_filter(path, bins, 3, k, bits, np.concatenate(genomes), goffs)
+    reads = []
+    for i in range(800):
+        b = int(rng.integers(0, bins)); L = int(rng.integers(k, k + 126)); s = int(rng.integers(0, 30000 - L))
+        r = genomes[b][s:s + L].copy()
+        for _ in range(int(rng.integers(0, 8))): r[int(rng.integers(0, L))] = rng.integers(0, 4)
+        if i % 4 == 0: r[L // 2:] = rng.integers(0, 4, L - L // 2)          # only the first half matches: weak bins that die late or survive
+        if i % 11 == 0: r[int(rng.integers(0, L))] = 4
+        if i % 2: r = np.where(r[::-1] < 4, 3 - r[::-1], 4).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    ibf = dy.Ibf.load(ctx, path); oibf = ob.OracleIbf(path); rd = dy.Reads(ctx, codes, offs)
+    for thr in (1, 2, 5, 10, 20, 29, 40, 64, 65, 90, 127, 200):
+        assert np.array_equal(ibf.query(rd, thr), oibf.query(codes, offs, thr)), thr
+    rd.close(); ibf.close(); oibf.close()
+
+
 @pytest.mark.parametrize("bins,bits,k", [(1024, 1 << 27, 12), (192, 1 << 24, 11), (256, 1 << 21, 10)])
 def test_ibf_low_thresholds_many_false_candidates(dy, ctx, ob, tmp_path, bins, bits, k):
     """More than 64 bins, reads under 256 k-mers and thresholds far below the k-mer count: the regime of the sparse verification
