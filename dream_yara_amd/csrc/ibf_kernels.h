@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
 
 // K1 for the headline shape: 64 bins or fewer (W = 1) and 65..127 k-mers per read (reads of 82..144 bases at k = 18).  Same
 // answers as k_ibf_query<7>; the second chunk of k-mers is fetched only as far as the decision needs it.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ibf_query_two(const u64 * __restrict__ words, IbfGeom g,
+__global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ words, IbfGeom g,
                                                        const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
                                                        u32 threshold, u64 * __restrict__ masks)
 {
@@ -277,65 +277,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
     const u32 nKmers = len - k + 1;             // at most 127, checked by the host for the whole batch
     const u64 kMask = (1ull << k) - 1;
-    u64 selW = 0;
-    for (u32 strand = 0; strand < 2; ++strand)
+    const u32 n0 = min(nKmers, 64u), tail = nKmers - n0;      // shorter reads of the batch simply have no tail
+    // The kernel is a chain of dependent gather rounds, so both strands go through every stage together: one round for the first
+    // 64 k-mers of both, one per tail group of both, then the verification.
+    // After the first 64 k-mers a bin is STRONG (count >= threshold: its verification can succeed on those k-mers alone), WEAK (it
+    // needs tail hits to reach the threshold) or dead.  Weak bins are false candidates almost always; the tail is gathered 8 k-mers
+    // at a time until they are all dead (bound = hits so far + k-mers not yet fetched).
+    bool firstIsN[2]; u64 hashA[2], m0[2], hashB[2] = {0, 0}, m1[2] = {0, 0};
+    u64 c0p[2][7]; u64 strong[2], weak[2]; u32 fetched[2] = {0, 0}; bool haveHashB[2] = {false, false};
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
     {
-        const bool firstIsN = strandCode(seq, len, 0, strand) > 3;
-            {   // ---- two chunks (65..127 k-mers), the headline shape: the second chunk (the "tail") is fetched only as far as needed.
-        // After the first 64 k-mers a bin is STRONG (count >= threshold: its verification below can succeed on those k-mers
-        // alone), WEAK (it needs tail hits to reach the threshold) or dead.  Weak bins are false candidates almost always;
-        // the tail is gathered 8 k-mers at a time until they are all dead (bound = hits so far + k-mers not yet fetched).
-        const u32 n0 = min(nKmers, 64u), tail = nKmers - n0;      // shorter reads of the batch simply have no tail
-        const u64 hashA = laneKmerHash(seq, len, strand, 0, lane, k, kMask, firstIsN);
-        const u64 m0 = lane < n0 ? words[ibfWordIndex(g, hashA, 0)] : 0;
-        u64 c0p[7];
-        waveBitSlicedSum(m0, c0p);
-        const u64 alive0 = planesGe(c0p, (int)threshold - (int)tail) & binMask;
-        if (!alive0) continue;
-        const u64 strong = planesGe(c0p, (int)threshold) & binMask;
-        u64 weak = alive0 & ~strong;
-        u64 hashB = 0, m1 = 0;
-        u32 fetched = 0;                                   // tail k-mers gathered so far (lanes [0, fetched))
-        bool haveHashB = false;
-        if (weak)
+        firstIsN[s] = strandCode(seq, len, 0, s) > 3;
+        hashA[s] = laneKmerHash(seq, len, s, 0, lane, k, kMask, firstIsN[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) m0[s] = lane < n0 ? words[ibfWordIndex(g, hashA[s], 0)] : 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+    {
+        waveBitSlicedSum(m0[s], c0p[s]);
+        const u64 alive0 = planesGe(c0p[s], (int)threshold - (int)tail) & binMask;
+        strong[s] = planesGe(c0p[s], (int)threshold) & binMask;
+        weak[s] = alive0 & ~strong[s];
+    }
+    if (weak[0] | weak[1])
+    {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (weak[s]) { hashB[s] = laneKmerHash(seq, len, s, 64, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
+        while ((weak[0] && fetched[0] < tail) || (weak[1] && fetched[1] < tail))
         {
-            hashB = laneKmerHash(seq, len, strand, 64, lane, k, kMask, firstIsN); haveHashB = true;
-            while (weak && fetched < tail)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (weak[s] && fetched[s] < tail)
+                {
+                    const u32 upTo = min(tail, fetched[s] + 8);
+                    if (lane >= fetched[s] && lane < upTo) m1[s] = words[ibfWordIndex(g, hashB[s], 0)];
+                    fetched[s] = upTo;
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
             {
-                const u32 upTo = min(tail, fetched + 8);
-                if (lane >= fetched && lane < upTo) m1 = words[ibfWordIndex(g, hashB, 0)];
-                fetched = upTo;
-                u64 todo = weak;
+                u64 todo = weak[s];
                 while (todo)
                 {
                     const u32 j = (u32)__ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    const u32 c1 = (u32)__popcll(ballot64((m1 >> j) & 1));
-                    if (planesGet(c0p, j) + c1 + (tail - fetched) < threshold) weak &= ~(1ull << j);
+                    const u32 c1 = (u32)__popcll(ballot64((m1[s] >> j) & 1));
+                    if (planesGet(c0p[s], j) + c1 + (tail - fetched[s]) < threshold) weak[s] &= ~(1ull << j);
                 }
             }
         }
-        // ---- phase B on strong and surviving weak bins (a surviving weak bin has count0 + count1 >= threshold, tail complete)
-        u64 und = strong | weak;
+    }
+    // ---- verification of strong and surviving weak bins (a surviving weak bin has count0 + count1 >= threshold, tail complete)
+    u64 selW = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+    {
+        u64 und = strong[s] | weak[s];
         while (und)
         {
             const u32 j = __ffsll((long long)und) - 1;
             und &= und - 1;
-            const u32 c0 = planesGet(c0p, j);
+            const u32 c0 = planesGet(c0p[s], j);
             u32 exactCnt = 0, seenCnt = 0;
             bool open = true;
             for (u32 chunk = 0; chunk < 2 && open; ++chunk)
             {
-                if (chunk == 1 && fetched < tail)
+                if (chunk == 1 && fetched[s] < tail)
                 {   // the verification of a strong bin did not reach the threshold on the first 64 k-mers: complete the tail
-                    if (!haveHashB) { hashB = laneKmerHash(seq, len, strand, 64, lane, k, kMask, firstIsN); haveHashB = true; }
-                    if (lane >= fetched && lane < tail) m1 = words[ibfWordIndex(g, hashB, 0)];
-                    fetched = tail;
+                    if (!haveHashB[s]) { hashB[s] = laneKmerHash(seq, len, s, 64, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
+                    if (lane >= fetched[s] && lane < tail) m1[s] = words[ibfWordIndex(g, hashB[s], 0)];
+                    fetched[s] = tail;
                 }
-                const u64 hash = chunk ? hashB : hashA;
-                const u64 mw = chunk ? m1 : m0;
+                const u64 hash = chunk ? hashB[s] : hashA[s];
+                const u64 mw = chunk ? m1[s] : m0[s];
                 // upper bound of the whole count: hits among the fetched k-mers + every k-mer not fetched yet
-                const u32 bound0 = c0 + (u32)__popcll(ballot64((m1 >> j) & 1)) + (tail - fetched);
+                const u32 bound0 = c0 + (u32)__popcll(ballot64((m1[s] >> j) & 1)) + (tail - fetched[s]);
                 u64 pending = ballot64((mw >> j) & 1);
                 while (pending && open)
                 {
@@ -353,8 +372,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 }
             }
         }
-        continue;
-    }
     }
     if (lane == 0) masks[read] = selW;
 }
