@@ -207,9 +207,10 @@ def main():
         # HBM traffic of K1 per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
         # narrow gathers are accounted at 64 B per request, calibrated on scripts/ubench_gather.hip: profiles/r01_fetch_size_calibration.json)
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01l_pmc_config2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01m_pmc_config2.json")
         if args.workload == "config2" and os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file)).get("void dy::k_ibf_query<7>", {})
+            allk = json.load(open(pmc_file))
+            pmc = allk.get("dy::k_ibf_query_two") or allk.get("void dy::k_ibf_query<7>") or {}
             if "FETCH_SIZE" in pmc:
                 traffic = (pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
         out = {
@@ -222,10 +223,10 @@ def main():
                        "mapped_fraction": mapped_fraction, "primary_in_true_bin": ok_bin,
                        "items_per_read": (stats["items"] if sm is None else sm.last["items"] / world) / wl["reads"], "raw_matches_per_read": stats["raw_matches"] / wl["reads"],
                        "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()}},
-            "roofline": {"kernel": "k_ibf_query" if W == 1 else "k_ibf_query_wide", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"kernel": "k_ibf_query_two" if W == 1 else "k_ibf_query_wide", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "note": ("algorithmic bytes %d B/read x %d reads per launch; " % (bytes_per_read, wl["reads"])) +
-                                 ("every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 87% busy at the same time (profiles/r01f_pmc_sq_config2.json)"
+                                 ("every 8 B word costs one 64 B HBM request at W=1; the kernel runs at the measured random-gather ceiling of the chip (55.6 G gathers/s = 3.56 TB/s of 64 B lines, scripts/ubench_gather.hip) and prunes gathers that cannot change the result; its vector ALUs are 78% busy at the same time (profiles/r01m_pmc_sq_k1.json)"
                                   if W == 1 else "W = %d words per hash position are fetched by adjacent lanes (k_ibf_query_wide); bound by vector-ALU issue, see DESIGN.md" % W)},
         }
         if args.paired:
