@@ -375,6 +375,42 @@ def test_variable_length_batch_matches_oracle(dy, ctx, ob, tmp_path):
     oidx.close()
 
 
+def test_long_reads_match_oracle(dy, ctx, ob, tmp_path):
+    """Reads of 1 000 .. 6 000 bases (the reference allows up to 8 191): the widest Myers instantiation (k_extend<128>), bands of up to
+    61 diagonals in the wave-parallel alignment DP, the 14-plane IBF counters."""
+    rng = np.random.default_rng(4096)
+    n_bins = 3
+    genomes = [rng.integers(0, 4, 60000, dtype=np.uint8) for _ in range(n_bins)]
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    fpath = str(tmp_path / "f.filter")
+    ob.build_filter(fpath, n_bins, 3, 16, 1 << 24, np.concatenate(genomes), goffs)
+    reads = []
+    for i in range(90):
+        L = int(rng.integers(1000, 6000)); b = int(rng.integers(0, n_bins)); s = int(rng.integers(0, 60000 - L - 40))
+        r = genomes[b][s:s + L + 30].copy()
+        for _ in range(int(rng.integers(0, 14))):
+            q = int(rng.integers(0, L)); kind = rng.random()
+            if kind < 0.6: r[q] = (r[q] + 1) & 3
+            elif kind < 0.8: r = np.concatenate([r[:q], r[q + 1:]])
+            else: r = np.concatenate([r[:q], rng.integers(0, 4, 1, dtype=np.uint8), r[q:]])
+        r = r[:L]
+        if i % 2: r = (3 - r[::-1]).astype(np.uint8)
+        if i % 7 == 0: r[int(rng.integers(0, L))] = 4
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    er = np.float32(0.005)
+    dev, stats = device_map(dy, ctx, idx_dir, n_bins, fpath, codes, offs, er, strata_rate=np.float32(0.001), read_len_for_thr=int(offs[-1]) // len(reads))
+    oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath)
+    o = ob.map_batch(oidx, oibf, codes, offs, er, np.float32(0.001))
+    assert stats["items"] == o[3]["items"] and stats["raw_matches"] == o[3]["raw_matches"]
+    assert_results_equal(dev, o[:3])
+    assert int(dev[0]["mapped"].sum()) > 50 and int((dev[0]["cigar_len"] > 1).sum()) > 20
+    oidx.close(); oibf.close()
+
+
 def test_empty_batch_and_unmappable_reads(dy, ctx, ob, tmp_path):
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 5000, dtype=np.uint8)
