@@ -411,6 +411,48 @@ def test_long_reads_match_oracle(dy, ctx, ob, tmp_path):
     oidx.close(); oibf.close()
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_more_than_64_bins_end_to_end(dy, ctx, ob, tmp_path, paired):
+    """130 bins (W = 3 mask words per read): work list, ordering, finalize and the paired-end stages with multi-word bin masks."""
+    rng = np.random.default_rng(130 + paired)
+    n_bins = 130
+    genomes = [rng.integers(0, 4, 6000, dtype=np.uint8) for _ in range(n_bins)]
+    genomes[7][1000:1400] = genomes[99][2000:2400]          # the same 400 bases in two bins of different mask words
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    fpath = str(tmp_path / "f.filter")
+    ob.build_filter(fpath, n_bins, 3, 14, 1 << 24, np.concatenate(genomes), goffs)
+    if paired:
+        codes, offs = _make_pairs(rng, genomes, 900, 100)
+    else:
+        reads = []
+        for i in range(2000):
+            b = 7 if i % 9 == 0 else int(rng.integers(0, n_bins)); s = 1050 + int(rng.integers(0, 200)) if i % 9 == 0 else int(rng.integers(0, 5890))
+            r = genomes[b][s:s + 100].copy()
+            for _ in range(int(rng.integers(0, 4))): r[int(rng.integers(0, 100))] = rng.integers(0, 4)
+            if i % 2: r = (3 - r[::-1]).astype(np.uint8)
+            reads.append(r.astype(np.uint8))
+        codes = np.concatenate(reads); offs = np.arange(2001, dtype=np.uint64) * np.uint64(100)
+    er, sr = np.float32(0.03), np.float32(0.01)
+    idx = dy.Index(ctx, idx_dir, n_bins); rd = dy.Reads(ctx, codes, offs); ibf = dy.Ibf.load(ctx, fpath)
+    ibf.query(rd, dy.threshold(er, 14, 100), want_masks=False)
+    res = dy.map_reads(ctx, idx, rd, dy.default_params(error_rate=er, strata_rate=sr, paired=1 if paired else 0))
+    dev = (res.reads(), res.matches(), res.cigars()); stats = ctx.stats()
+    res.close(); rd.close(); idx.close(); ibf.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath)
+    o = ob.map_batch(oidx, oibf, codes, offs, er, sr, paired=paired)
+    assert stats["items"] == o[3]["items"] and stats["raw_matches"] == o[3]["raw_matches"]
+    if paired:
+        assert np.array_equal(dev[0]["paired"], o[0]["paired"]) and np.array_equal(dev[0]["pair_prob"], o[0]["pair_prob"])
+    assert_results_equal(dev, o[:3])
+    if not paired:
+        assert stats["items"] > offs.size - 1                # some reads go to more than one bin
+        assert int((dev[0]["best_count"] > 1).sum()) > 100   # the shared segment maps to bins 7 and 99
+    oidx.close(); oibf.close()
+
+
 def test_empty_batch_and_unmappable_reads(dy, ctx, ob, tmp_path):
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 5000, dtype=np.uint8)
