@@ -861,14 +861,14 @@ def test_cli_errors_exit_1_with_the_tool_name(product_build, small_filter, tmp_p
 
 
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
-@pytest.mark.parametrize("strata", [0.0, 0.02])
-def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata):
+@pytest.mark.parametrize("strata,n_bins", [(0.0, 6), (0.02, 6), (0.0, 70)])
+def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata, n_bins):
     """two ranks (both on cuda:0, exchanges over gloo) each hold the FM structures of half the bins; the
     merged per-read results equal the single-GPU run on the concatenated batch (which the other tests tie to the oracle)."""
     import sys, json
     rng = np.random.default_rng(99)
-    n_bins, k = 6, 16
-    genomes, fam = _repeat_genomes(rng, n_bins, 60000)
+    k = 16
+    genomes, fam = _repeat_genomes(rng, n_bins, 60000 if n_bins < 10 else 8000)      # 70 bins: two mask words per read
     idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
     for b, g in enumerate(genomes):
         ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
