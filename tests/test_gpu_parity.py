@@ -453,6 +453,31 @@ def test_more_than_64_bins_end_to_end(dy, ctx, ob, tmp_path, paired):
     oidx.close(); oibf.close()
 
 
+@pytest.mark.parametrize("hits_threshold", [20, 100000])
+def test_hits_threshold_parameter(dy, ctx, ob, tmp_path, hits_threshold):
+    """classifyReads' threshold (reference src/mapper_classifier.h:111-155, option default 300): a low value re-seeds most repeat
+    reads, a huge one none — both equal the oracle."""
+    rng = np.random.default_rng(300 + hits_threshold % 7)
+    n_bins = 4
+    genomes, fam = _repeat_genomes(rng, n_bins, 40000)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    codes, offs = _sample_reads(rng, genomes, fam, 900, 100, 3)
+    er = np.float32(0.03)
+    idx = dy.Index(ctx, idx_dir, n_bins); rd = dy.Reads(ctx, codes, offs)
+    params = dy.default_params(error_rate=er, hits_threshold=hits_threshold); params.use_filter = 0
+    res = dy.map_reads(ctx, idx, rd, params)
+    dev = (res.reads(), res.matches(), res.cigars()); stats = ctx.stats()
+    res.close(); rd.close(); idx.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins)
+    o = ob.map_batch(oidx, None, codes, offs, er, hits_threshold=hits_threshold)
+    assert stats["items"] == o[3]["items"] and stats["raw_matches"] == o[3]["raw_matches"]
+    assert_results_equal(dev, o[:3])
+    assert (stats["hard_items"] > 300) if hits_threshold == 20 else (stats["hard_items"] < 50)      # the poly-A reads exceed even 100 000 hits
+    oidx.close()
+
+
 def test_empty_batch_and_unmappable_reads(dy, ctx, ob, tmp_path):
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 5000, dtype=np.uint8)
