@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdyhip.so")
+LIB_PATH = os.environ.get("DY_LIB") or os.path.join(_HERE, "csrc", "libdyhip.so")
 
 DY_OK = 0
 DY_ENODEVICE = -3

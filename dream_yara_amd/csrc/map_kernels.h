@@ -392,10 +392,10 @@ struct MatchSink
 
 // extend() + _addMatchImpl() for one located seed occurrence (reference src/find_extender.h:262-403, src/mapper_extender.h:293-308).
 // `seq` is the read sequence of the seed's strand (forward or reverse complement), readable front to back.
-template <int NW>
-__device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
-                                 const u8 * __restrict__ seq, u32 len, u32 strand,
-                                 u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
+// `emit(matchBegin, matchLength, errors)` is called once if the occurrence extends to a match.
+template <int NW, typename TEmit>
+__device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
+                                                  const u8 * __restrict__ seq, u32 len, u32 needleBegin, u32 maxErrors, TEmit emit)
 {
     const u8 * __restrict__ ctg = binContigs + binLimits[contig];
     const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
@@ -479,36 +479,29 @@ __device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 *
             if (errors > maxErrors) return;
         }
     }
-    // _addMatchImpl
-    RawMatch m;
-    m.read = read; m.begin = matchBegin; m.len = (u16)(matchEnd - matchBegin); m.errors = (u8)errors; m.strand = (u8)strand;
-    m.bin = (u16)bin; m.contig = (u16)contig;
-    if (st.nbuf == 0) { st.buf0 = m; st.nbuf = 1; }
-    else if (st.nbuf == 1) { st.buf1 = m; st.nbuf = 2; }
-    else
-    {
-        const u32 slot = atomicAdd(sink.poolCount, 1u);
-        if (slot < sink.poolCap) { sink.pool[slot] = m; atomicAdd(&sink.readMatchCount[read], 1u); }
-        else atomicExch(sink.overflow, 1u);
-    }
-    if (errors < st.minErrors) st.minErrors = errors;
+    emit(matchBegin, matchEnd - matchBegin, errors);
 }
 
-// _extendHitImpl: every SA position of one hit range (reference src/mapper_extender.h:215-286)
+// one item per lane: _addMatchImpl into the lane's ItemState
 template <int NW>
-__device__ void extendRange(const BinView & b, u32 lo, u32 hi, u32 seedLen, const u8 * __restrict__ seq, u32 len, u32 strand,
-                            u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
+__device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
+                                 const u8 * __restrict__ seq, u32 len, u32 strand,
+                                 u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
 {
-    if (sink.debugFlags & 2) return;
-    for (u32 row = lo; row < hi; ++row)
-    {
-        u32 contig, x;
-        fmLocate(b, row, contig, x);
-        if (sink.debugFlags & 1) { if (x == 0xFFFFFFFFu) st.minErrors = 0; continue; }
-        const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
-        if (clen - x < seedLen) continue;                       // suffixLength < seedLength
-        extendOccurrence<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, seq, len, strand, needleBegin, maxErrors, read, bin, st, sink);
-    }
+    extendOccurrenceT<NW>(binContigs, binLimits, contig, hayBegin, seedLen, seq, len, needleBegin, maxErrors, [&](u32 matchBegin, u32 matchLen, u32 errors) {
+        RawMatch m;
+        m.read = read; m.begin = matchBegin; m.len = (u16)matchLen; m.errors = (u8)errors; m.strand = (u8)strand;
+        m.bin = (u16)bin; m.contig = (u16)contig;
+        if (st.nbuf == 0) { st.buf0 = m; st.nbuf = 1; }
+        else if (st.nbuf == 1) { st.buf1 = m; st.nbuf = 2; }
+        else
+        {
+            const u32 slot = atomicAdd(sink.poolCount, 1u);
+            if (slot < sink.poolCap) { sink.pool[slot] = m; atomicAdd(&sink.readMatchCount[read], 1u); }
+            else atomicExch(sink.overflow, 1u);
+        }
+        if (errors < st.minErrors) st.minErrors = errors;
+    });
 }
 
 // Hamming backtracking over the FM trie with at most maxErr substitutions (SeqAn find(..., Backtracking<HammingDistance>),
@@ -690,56 +683,6 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
     }
 }
 
-// Hard item: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2), Hamming backtracking in the FM index.
-template <int NW>
-__device__ void extendHardItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
-                               const uint2 * __restrict__ hits0, const MatchSink & sink, ItemState & st)
-{
-    const u8 * seq = rd.seqs + rd.offs[read];
-    const u8 * seqRc = rd.seqsRc + rd.offs[read];
-    const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
-    const u32 readErrors = readErrorsOf(len, prm.errorRate), readStrata = readStrataOf(len, prm.strataRate);
-    const BinView b = makeBinView(ix, bin);
-    const u32 seedErrors = classifyItem(hits0 + (size_t)item * 2 * S0, S0, prm);
-    const u32 cntB = seedCountOf(readErrors, seedErrors);
-    if (len < cntB) return;
-    const u32 seedLen = len / cntB;
-    // rounds: E = 0 (exact search of the long seeds), 1, and 2 (only bucket 2, only above LOW sensitivity)
-    for (u32 E = 0; E <= 2 && !st.mapped; ++E)
-    {
-        if (E > seedErrors) break;
-        if (E == 2 && prm.sensitivity == 0) break;
-        // per-seed hit counts (findSeeds<E> + rankSeeds)
-        u32 counts[2][MAX_SEEDS];
-        for (u32 strand = 0; strand < 2; ++strand)
-            for (u32 k = 0; k < cntB; ++k)
-            {
-                u32 c = 0;
-                fmBacktrack(b, seq, len, strand, (cntB - 1 - k) * seedLen, seedLen, E, [&](u32 lo, u32 hi) { c += hi - lo; });
-                counts[strand][k] = c;
-            }
-        u32 done[2] = {0, 0};
-        for (u32 rank = 0; rank < cntB && !st.mapped; ++rank)
-        {
-            for (u32 strand = 0; strand < 2; ++strand)
-            {
-                u32 best = 0xFFFFFFFFu, bestId = 0;
-                for (u32 k = 0; k < cntB; ++k)
-                {
-                    if (done[strand] >> k & 1) continue;
-                    if (counts[strand][k] < best) { best = counts[strand][k]; bestId = k; }
-                }
-                done[strand] |= 1u << bestId;
-                const u32 off = (cntB - 1 - bestId) * seedLen;
-                fmBacktrack(b, seq, len, strand, off, seedLen, E, [&](u32 lo, u32 hi) {
-                    extendRange<NW>(b, lo, hi, seedLen, strand ? seqRc : seq, len, strand, off, readErrors, read, bin, st, sink);
-                });
-            }
-            if (st.minErrors + readStrata <= rank * (E + 1)) st.mapped = true;
-        }
-    }
-}
-
 #ifndef DY_K3_WAVES
 #define DY_K3_WAVES 4      // waves per SIMD the easy-path kernel is compiled for at NW <= 2 (measured: 4 -> 1.10 ms, 5 -> 1.11 ms, 6 -> 1.20 ms: spills eat the gain)
 #endif
@@ -764,6 +707,101 @@ __device__ __forceinline__ void flushWaveMatches(const ItemState & st, u32 read,
     if (cnt >= 2)
     {
         if (first + 1 < sink.poolCap) { sink.pool[first + 1] = st.buf1; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+}
+
+// Hard item: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2), Hamming backtracking in the FM index.
+// ONE WAVEFRONT PER ITEM: a re-seeded read has hundreds to hundreds of thousands of seed occurrences, so the trie walk (cheap) is
+// done by all lanes in step and the SA rows of every leaf are dealt to the 64 lanes, each extending its own occurrence.  A rank is
+// a unit (all hits of the rank's two seeds are extended, then minErrors decides the exit), so the order inside it is free; the
+// minimum over the lanes is taken after each rank.  Matches go to the pool step by step (st's buffers stay unused).
+template <int NW>
+__device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
+                                   const uint2 * __restrict__ hits0, const MatchSink & sink, ItemState & st, u32 lane)
+{
+    const u8 * seq = rd.seqs + rd.offs[read];
+    const u8 * seqRc = rd.seqsRc + rd.offs[read];
+    const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
+    const u32 readErrors = readErrorsOf(len, prm.errorRate), readStrata = readStrataOf(len, prm.strataRate);
+    const BinView b = makeBinView(ix, bin);
+    const u32 seedErrors = classifyItem(hits0 + (size_t)item * 2 * S0, S0, prm);
+    const u32 cntB = seedCountOf(readErrors, seedErrors);
+    if (len < cntB) return;
+    const u32 seedLen = len / cntB;
+    // rounds: E = 0 (exact search of the long seeds), 1, and 2 (only bucket 2, only above LOW sensitivity)
+    for (u32 E = 0; E <= 2 && !st.mapped; ++E)
+    {
+        if (E > seedErrors) break;
+        if (E == 2 && prm.sensitivity == 0) break;
+        // per-seed hit counts (findSeeds<E> + rankSeeds), the same in every lane
+        u32 counts[2][MAX_SEEDS];
+        for (u32 strand = 0; strand < 2; ++strand)
+            for (u32 k = 0; k < cntB; ++k)
+            {
+                u32 c = 0;
+                fmBacktrack(b, seq, len, strand, (cntB - 1 - k) * seedLen, seedLen, E, [&](u32 lo, u32 hi) { c += hi - lo; });
+                counts[strand][k] = c;
+            }
+        u32 done[2] = {0, 0};
+        for (u32 rank = 0; rank < cntB && !st.mapped; ++rank)
+        {
+            for (u32 strand = 0; strand < 2; ++strand)
+            {
+                u32 best = 0xFFFFFFFFu, bestId = 0;
+                for (u32 k = 0; k < cntB; ++k)
+                {
+                    if (done[strand] >> k & 1) continue;
+                    if (counts[strand][k] < best) { best = counts[strand][k]; bestId = k; }
+                }
+                done[strand] |= 1u << bestId;
+                const u32 off = (cntB - 1 - bestId) * seedLen;
+                const u8 * sq = strand ? seqRc : seq;
+                fmBacktrack(b, seq, len, strand, off, seedLen, E, [&](u32 lo, u32 hi) {
+                    if (sink.debugFlags & 2) return;
+                    for (u32 base = lo; base < hi; base += 64)
+                    {   // lanes beyond the leaf idle for this step; the loop bound is the same in every lane
+                        const u32 row = base + lane;
+                        u32 got = 0, mBegin = 0, mLen = 0, mErrors = 0, mContig = 0;
+                        if (row < hi)
+                        {
+                            u32 contig, x;
+                            fmLocate(b, row, contig, x);
+                            const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
+                            if (clen - x >= seedLen && !(sink.debugFlags & 1))      // suffixLength >= seedLength
+                                extendOccurrenceT<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, sq, len, off, readErrors,
+                                                      [&](u32 matchBegin, u32 matchLen, u32 errors) { got = 1; mBegin = matchBegin; mLen = matchLen; mErrors = errors; mContig = contig; });
+                        }
+                        // every lane holds at most one new match of the SAME read: one pool reservation and one per-read count update per
+                        // step for the whole wavefront (a repeat read yields 10^3..10^5 matches; same-address atomics are served one by one)
+                        const u64 have = __ballot(got != 0);
+                        if (have)
+                        {
+                            const u32 total = (u32)__popcll(have);
+                            u32 first = 0;
+                            if (lane == 0)
+                            {
+                                first = atomicAdd(sink.poolCount, total);
+                                if (first + total <= sink.poolCap) atomicAdd(&sink.readMatchCount[read], total); else atomicExch(sink.overflow, 1u);
+                            }
+                            first = __shfl(first, 0, 64);
+                            if (got && first + total <= sink.poolCap)
+                            {
+                                RawMatch m;
+                                m.read = read; m.begin = mBegin; m.len = (u16)mLen; m.errors = (u8)mErrors; m.strand = (u8)strand;
+                                m.bin = (u16)bin; m.contig = (u16)mContig;
+                                sink.pool[first + (u32)__popcll(have & ((1ull << lane) - 1))] = m;
+                            }
+                            if (got && mErrors < st.minErrors) st.minErrors = mErrors;
+                        }
+                    }
+                });
+            }
+            // ReadsContext::minErrors is one value per read
+            u32 mn = st.minErrors;
+            for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (u32)__shfl_xor(mn, o, 64));
+            st.minErrors = mn;
+            if (st.minErrors + readStrata <= rank * (E + 1)) st.mapped = true;
+        }
     }
 }
 
@@ -822,22 +860,13 @@ __global__ __launch_bounds__(256) void k_extend_hard(IndexView ix, ReadsView rd,
 {
     const u32 lane = threadIdx.x & 63;
     const u32 n = *hardCount;
-    // Hard items diverge (backtracking depth, hit counts), and a wavefront runs as long as the sum of its lanes' distinct
-    // paths: spread the list over all waves of the grid, as few items per wave as the list length allows.
     const u32 totalWaves = gridDim.x * (blockDim.x >> 6), waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const u32 perWave = min(64u, (n + totalWaves - 1) / totalWaves);
-    for (u32 first = waveId * perWave; first < n; first += totalWaves * perWave)
-    {
-        const u32 i = first + lane;
+    for (u32 i = waveId; i < n; i += totalWaves)
+    {   // one wavefront per re-seeded item (see extendHardItemWave)
         ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
-        u32 read = 0;
-        if (lane < perWave && i < n)
-        {
-            const u32 item = hardList[i];
-            read = itemRead[item];
-            extendHardItem<NW>(ix, rd, item, read, itemBin[item], S0, prm, hits0, sink, st);
-        }
-        flushWaveMatches(st, read, sink, lane);
+        const u32 item = hardList[i];
+        const u32 read = itemRead[item];
+        extendHardItemWave<NW>(ix, rd, item, read, itemBin[item], S0, prm, hits0, sink, st, lane);
     }
 }
 
