@@ -339,8 +339,11 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         ctx->maux.reserve(setCap * 2 * 4 + 64);
         takeBuffer(ctx, res->outSet, setCap * sizeof(OutMatch) + 64);
         const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
+        // reads with more matches than this are aggregated by a whole 1024-thread block instead of one wavefront (repeats, low-complexity runs)
+        const u32 blockMin = getenv("DY_FINALIZE_BLOCK_MIN") ? (u32)atoi(getenv("DY_FINALIZE_BLOCK_MIN")) : 2048u;
+        const u32 hugeBlocks = 512;
         const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
-        ctx->dp.reserve(dpStride * finWaves + 64);
+        ctx->dp.reserve(dpStride * (finWaves + hugeBlocks) + 64);
         FinalizeArgs fa;
         fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.readSeqsRc = rv.seqsRc; fa.nReads = nReads;
         fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
@@ -371,7 +374,8 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             const size_t traceLds = (size_t)traceRows * dpThreads * (narrowBand ? 4 : 8);
             if (narrowBand) hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
             else hipLaunchKernelGGL((k_finalize_small<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
-            hipLaunchKernelGGL(k_finalize, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa);
+            hipLaunchKernelGGL(k_finalize_t<BlockGroup>, dim3(hugeBlocks), dim3(1024), 0, ctx->side[0], fa, blockMin + 1, 0xFFFFFFFFu, finWaves);
+            hipLaunchKernelGGL(k_finalize_t<WaveGroup>, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa, 0u, blockMin, 0u);
             HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
             HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
             hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount);

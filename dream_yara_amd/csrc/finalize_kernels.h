@@ -510,31 +510,145 @@ __host__ __device__ inline size_t dpScratchBytes(u32 maxReadLen, u32 maxErrors)
     return (((size_t)(maxReadLen + 1) * B + 3) & ~(size_t)3) + 6 * B * sizeof(int) + 4 * (size_t)maxReadLen + 4 * maxErrors + 32;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
+// ---- who works on one read in k_finalize_t: a wavefront (almost every read) or a whole 1024-thread block (reads with thousands of
+// matches: repeats, low-complexity runs — one wavefront would sort them alone for seconds).  Same code, different primitives.
+struct WaveGroup
 {
-    const u32 lane = threadIdx.x & 63;
-    const u32 gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const u32 nWaves = (gridDim.x * blockDim.x) >> 6;
+    enum : u32 { SIZE = 64, BLOCK = 256, PER_BLOCK = 4 };
+    __device__ static __forceinline__ u32 tid() { return threadIdx.x & 63; }
+    __device__ static __forceinline__ u32 slot() { return threadIdx.x >> 6; }
+    __device__ static __forceinline__ u32 groupId() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
+    __device__ static __forceinline__ u32 groupCount() { return (gridDim.x * blockDim.x) >> 6; }
+    __device__ static __forceinline__ bool alignerWave() { return true; }
+    __device__ static __forceinline__ void fence() { waveFence(); }
+    __device__ static __forceinline__ u32 sum(u32 v) { return waveSum32(v); }
+    __device__ static __forceinline__ u32 minv(u32 v) { return waveMin32(v); }
+    __device__ static __forceinline__ u32 push(bool pred, u32 & base) { return wavePush(pred, threadIdx.x & 63, base); }
+    __device__ static __forceinline__ u32 count(bool pred) { return (u32)__popcll(__ballot(pred)); }
+    // rank of this thread among the threads with pred (valid if pred); total = their number
+    __device__ static __forceinline__ u32 rank(bool pred, u32 & total)
+    {
+        const u64 b = __ballot(pred);
+        total = (u32)__popcll(b);
+        return (u32)__popcll(b & ((1ull << (threadIdx.x & 63)) - 1));
+    }
+    __device__ static __forceinline__ int firstTrue(bool pred) { const u64 b = __ballot(pred); return b ? __ffsll((long long)b) - 1 : -1; }
+    __device__ static __forceinline__ u32 bcast(u32 v, u32 src) { return __shfl(v, src, 64); }
+};
+
+struct BlockGroup
+{   // every thread of the block must make the same sequence of calls
+    enum : u32 { SIZE = 1024, BLOCK = 1024, PER_BLOCK = 1, NWAVES = 16 };
+    __device__ static __forceinline__ u32 tid() { return threadIdx.x; }
+    __device__ static __forceinline__ u32 slot() { return 0; }
+    __device__ static __forceinline__ u32 groupId() { return blockIdx.x; }
+    __device__ static __forceinline__ u32 groupCount() { return gridDim.x; }
+    __device__ static __forceinline__ bool alignerWave() { return threadIdx.x < 64; }
+    __device__ static __forceinline__ void fence() { __syncthreads(); }
+    __device__ static __forceinline__ u32 sum(u32 v)
+    {
+        __shared__ u32 part[NWAVES];
+        v = waveSum32(v);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        u32 t = 0;
+#pragma unroll
+        for (u32 k = 0; k < NWAVES; ++k) t += part[k];
+        __syncthreads();
+        return t;
+    }
+    __device__ static __forceinline__ u32 minv(u32 v)
+    {
+        __shared__ u32 part[NWAVES];
+        v = waveMin32(v);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        u32 t = 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 k = 0; k < NWAVES; ++k) t = min(t, part[k]);
+        __syncthreads();
+        return t;
+    }
+    __device__ static __forceinline__ u32 rank(bool pred, u32 & total)
+    {
+        __shared__ u32 part[NWAVES];
+        const u64 b = __ballot(pred);
+        const u32 w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) part[w] = (u32)__popcll(b);
+        __syncthreads();
+        u32 before = 0, t = 0;
+#pragma unroll
+        for (u32 k = 0; k < NWAVES; ++k) { const u32 c = part[k]; before += k < w ? c : 0; t += c; }
+        __syncthreads();
+        total = t;
+        return before + (u32)__popcll(b & ((1ull << (threadIdx.x & 63)) - 1));
+    }
+    __device__ static __forceinline__ u32 push(bool pred, u32 & base) { u32 total; const u32 r = rank(pred, total); const u32 slot = base + r; base += total; return slot; }
+    __device__ static __forceinline__ u32 count(bool pred) { u32 total; (void)rank(pred, total); return total; }
+    __device__ static __forceinline__ int firstTrue(bool pred) { const u32 m = minv(pred ? threadIdx.x : 0xFFFFFFFFu); return m == 0xFFFFFFFFu ? -1 : (int)m; }
+    __device__ static __forceinline__ u32 bcast(u32 v, u32 src)
+    {
+        __shared__ u32 x;
+        if (threadIdx.x == src) x = v;
+        __syncthreads();
+        const u32 r = x;
+        __syncthreads();
+        return r;
+    }
+};
+
+// waveSort's global-memory path for any group
+template <typename G, typename TLess>
+__device__ void groupSort(u32 * idx, u32 cnt, TLess less)
+{
+    if (G::SIZE == 64) { waveSort(idx, cnt, threadIdx.x & 63, less); return; }
+    if (cnt <= 1) return;
+    for (u32 k = 2; (k >> 1) < cnt; k <<= 1)
+    {
+        for (u32 j = k >> 1, first = 1; j > 0; j >>= 1, first = 0)
+        {
+            for (u32 i = G::tid(); i < cnt; i += G::SIZE)
+            {
+                const u32 l = first ? (i ^ (k - 1)) : (i ^ j);
+                if (l > i && l < cnt)
+                {
+                    const u32 a = idx[i], b = idx[l];
+                    if (less(b, a)) { idx[i] = b; idx[l] = a; }
+                }
+            }
+            G::fence();
+        }
+    }
+}
+
+// Reads of the complex list with minN <= #matches <= maxN, one group G per read.
+template <typename G>
+__global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 minN, u32 maxN, u32 dpSlabBase)
+{
+    const u32 lane = G::tid();
+    const u32 gwave = G::groupId();
+    const u32 nWaves = G::groupCount();
     // alignment scratch: LDS when the banded matrices of this batch fit (they do for short reads), else the global slab
     enum { DP_LDS_BYTES = 4096, SMALL_N = 32 };
-    __shared__ __attribute__((aligned(16))) u8 sDp[4][DP_LDS_BYTES];
-    u8 * dp = A.dpStride <= DP_LDS_BYTES ? sDp[threadIdx.x >> 6] : A.dpScratch + (size_t)gwave * A.dpStride;
+    __shared__ __attribute__((aligned(16))) u8 sDp[G::PER_BLOCK][DP_LDS_BYTES];
+    u8 * dp = A.dpStride <= DP_LDS_BYTES ? sDp[G::slot()] : A.dpScratch + (size_t)(dpSlabBase + gwave) * A.dpStride;
     // reads with few matches (almost all of them) keep every working array in LDS; the rest use the global scratch
-    __shared__ RawMatch sE[4][SMALL_N];
-    __shared__ RawMatch sM[4][3 * SMALL_N];
-    __shared__ u32 sIdx[4][8 * SMALL_N];
+    __shared__ RawMatch sE[G::PER_BLOCK][SMALL_N];
+    __shared__ RawMatch sM[G::PER_BLOCK][3 * SMALL_N];
+    __shared__ u32 sIdx[G::PER_BLOCK][8 * SMALL_N];
 
     const u32 nList = *A.complexCount;
     for (u32 li = gwave; li < nList; li += nWaves)
     {
         const u32 read = A.complexList[li];
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
+        if (n < minN || n > maxN) continue;
         const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
         const u8 * seq = A.readSeqs + A.readOffs[read];
         ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
         if (n == 0) { if (lane == 0) A.out[read] = ro; continue; }
-        const bool small = n <= SMALL_N;
-        const u32 wv = threadIdx.x >> 6;
+        const bool small = G::SIZE == 64 && n <= SMALL_N;
+        const u32 wv = G::slot();
         if (small && lane < n) sE[wv][lane] = A.gp[s0 + lane];
         const RawMatch * E = small ? sE[wv] : A.gp + s0;
         u32 * idxA = small ? sIdx[wv] : A.aux + (size_t)4 * s0;                 // n entries: all matches of the read in child END order
@@ -544,9 +658,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
         u32 * idxF = idxM + (size_t)3 * n;                                      // 3n
 
         // ---- child mappers: one (read, bin) segment at a time, bins in ascending order
-        for (u32 i = lane; i < n; i += 64) idxA[i] = i;
-        waveFence();
-        waveSort(idxA, n, lane, [&](u32 a, u32 b) { return lessEnd(E[a], a, E[b], b); });
+        for (u32 i = lane; i < n; i += G::SIZE) idxA[i] = i;
+        G::fence();
+        groupSort<G>(idxA, n, [&](u32 a, u32 b) { return lessEnd(E[a], a, E[b], b); });
         u32 nM = 0;
         u32 winErr = 256, winRank = 0;                 // copyCigars: last processed bin among those with the minimal errors
         u32 p0 = 0;
@@ -554,11 +668,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
         {
             const u32 bin = E[idxA[p0]].bin;
             u32 cntBin = 0;
-            for (u32 p = p0 + lane; p < n; p += 64) cntBin += E[idxA[p]].bin == bin;
-            const u32 p1 = p0 + waveSum32(cntBin);
+            for (u32 p = p0 + lane; p < n; p += G::SIZE) cntBin += E[idxA[p]].bin == bin;
+            const u32 p1 = p0 + G::sum(cntBin);
             // pass 1 (ContigEnd): unique by (contig, strand, end); stale tail = sorted positions >= n1
             u32 n1 = 0;
-            for (u32 base = p0; base < p1; base += 64)
+            for (u32 base = p0; base < p1; base += G::SIZE)
             {
                 const u32 p = base + lane;
                 bool first = false;
@@ -568,20 +682,20 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                     first = p == p0;
                     if (!first) { const RawMatch b = E[idxA[p - 1]]; first = !(sameBinContigStrand(a, b) && mEnd(a) == mEnd(b)); }
                 }
-                const u32 slot = wavePush(first, lane, n1);
+                const u32 slot = G::push(first, n1);
                 if (first) idxB[slot] = idxA[p];
             }
-            for (u32 base = p0 + n1; base < p1; base += 64)
+            for (u32 base = p0 + n1; base < p1; base += G::SIZE)
             {
                 const u32 p = base + lane;
-                const u32 slot = wavePush(p < p1, lane, nM);
+                const u32 slot = G::push(p < p1, nM);
                 if (p < p1) M[slot] = E[idxA[p]];
             }
-            waveFence();
+            G::fence();
             // pass 2 (ContigBegin) over the n1 survivors
-            waveSort(idxB, n1, lane, [&](u32 a, u32 b) { return lessBegin(E[a], a, E[b], b); });
+            groupSort<G>(idxB, n1, [&](u32 a, u32 b) { return lessBegin(E[a], a, E[b], b); });
             u32 n2 = 0, myMin = 255;
-            for (u32 base = 0; base < n1; base += 64)
+            for (u32 base = 0; base < n1; base += G::SIZE)
             {
                 const u32 q = base + lane;
                 bool first = false;
@@ -592,19 +706,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                     if (!first) { const RawMatch b = E[idxB[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
                     if (first) myMin = min(myMin, (u32)a.errors);
                 }
-                const u64 bal = __ballot(first);
-                n2 += (u32)__popcll(bal);
+                n2 += G::count(first);
             }
-            const u32 minErr = waveMin32(myMin);
-            for (u32 base = n2; base < n1; base += 64)
+            const u32 minErr = G::minv(myMin);
+            for (u32 base = n2; base < n1; base += G::SIZE)
             {   // stale tail of pass 2
                 const u32 q = base + lane;
-                const u32 slot = wavePush(q < n1, lane, nM);
+                const u32 slot = G::push(q < n1, nM);
                 if (q < n1) M[slot] = E[idxB[q]];
             }
             // rankMatches (child): primary = rnd-th co-optimal match in coordinate order among the unique ones
             u32 nOptB = 0;
-            for (u32 base = 0; base < n1; base += 64)
+            for (u32 base = 0; base < n1; base += G::SIZE)
             {
                 const u32 q = base + lane;
                 bool opt = false;
@@ -615,12 +728,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                     if (!first) { const RawMatch b = E[idxB[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
                     opt = first && a.errors == minErr;
                 }
-                nOptB += (u32)__popcll(__ballot(opt));
+                nOptB += G::count(opt);
             }
             const u32 pickB = libcxxFirstUniform(nOptB);
             u32 optSeen = 0;
             const u32 binRank = A.binOrderRank[bin] + 1;
-            for (u32 base = 0; base < n1; base += 64)
+            for (u32 base = 0; base < n1; base += G::SIZE)
             {
                 const u32 q = base + lane;
                 RawMatch a; bool first = false;
@@ -631,33 +744,36 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                     if (!first) { const RawMatch b = E[idxB[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
                 }
                 const bool opt = first && a.errors == minErr;
-                const u64 balOpt = __ballot(opt);
-                const u32 myOptRank = optSeen + (u32)__popcll(balOpt & ((1ull << lane) - 1));
-                optSeen += (u32)__popcll(balOpt);
+                u32 optHere;
+                const u32 myOptRank = optSeen + G::rank(opt, optHere);
+                optSeen += optHere;
                 const bool isPrim = opt && myOptRank == pickB;
-                const u64 balPrim = __ballot(isPrim);
-                if (balPrim)
+                const int plFound = G::firstTrue(isPrim);
+                if (plFound >= 0)
                 {
-                    const u32 pl = __ffsll((long long)balPrim) - 1;     // the lane holding this bin's primary
+                    const u32 pl = (u32)plFound;                        // the thread holding this bin's primary
                     const bool winner = minErr < winErr || (minErr == winErr && binRank > winRank);   // uniform
                     // broadcast the primary so that the whole wave can align it
-                    const u32 pBegin = __shfl(a.begin, pl, 64), pLen = __shfl((u32)a.len, pl, 64), pErr = __shfl((u32)a.errors, pl, 64);
-                    const u32 pStrand = __shfl((u32)a.strand, pl, 64), pContig = __shfl((u32)a.contig, pl, 64);
+                    const u32 pBegin = G::bcast(q < n1 ? a.begin : 0u, pl), pLen = G::bcast(q < n1 ? (u32)a.len : 0u, pl), pErr = G::bcast(q < n1 ? (u32)a.errors : 0u, pl);
+                    const u32 pStrand = G::bcast(q < n1 ? (u32)a.strand : 0u, pl), pContig = G::bcast(q < n1 ? (u32)a.contig : 0u, pl);
                     const bool gapped = !(pErr == 0 || (pErr == 1 && pLen == readLen));
                     if (gapped && !(A.debugFlags & 1))
                     {   // alignMatches: CIGAR + shrink
                         const BinDesc & bd = A.bins[bin];
                         const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + pContig] + pBegin;
                         int cb = 0, ce = (int)pLen;
-                        u32 nc;
+                        u32 nc = 0;
                         if (2 * pErr + 1 <= 64)
-                            nc = alignMatchWave(ctg, (int)pLen, seq, readLen, pStrand, (int)pErr, dp, winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, lane);
+                        {   // one wavefront aligns (lane = diagonal); a block hands the result round
+                            if (G::alignerWave())
+                                nc = alignMatchWave(ctg, (int)pLen, seq, readLen, pStrand, (int)pErr, dp, winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, threadIdx.x & 63);
+                            if (G::SIZE != 64) { nc = G::bcast(nc, 0); cb = (int)G::bcast((u32)cb, 0); ce = (int)G::bcast((u32)ce, 0); }
+                        }
                         else
                         {
-                            nc = 0;
                             if (lane == 0)
                                 nc = alignMatchDevice(ctg, (int)pLen, seq, readLen, pStrand, (int)pErr, dp, winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
-                            nc = __shfl(nc, 0, 64); cb = __shfl(cb, 0, 64); ce = __shfl(ce, 0, 64);
+                            nc = G::bcast(nc, 0); cb = (int)G::bcast((u32)cb, 0); ce = (int)G::bcast((u32)ce, 0);
                         }
                         if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
                         if (lane == pl) { a.begin += (u32)cb; a.len = (u16)ce; }      // sic: endPosition(contigGaps), reference src/mapper_aligner.h:213-218
@@ -669,18 +785,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                     }
                     if (winner) { winErr = minErr; winRank = binRank; }
                 }
-                const u32 slot = wavePush(first, lane, nM);
+                const u32 slot = G::push(first, nM);
                 if (first) M[slot] = a;
             }
-            waveFence();
+            G::fence();
             p0 = p1;
         }
         // ---- main mapper: aggregateMatches + rankMatches2 over the union
-        for (u32 i = lane; i < nM; i += 64) idxM[i] = i;
-        waveFence();
-        waveSort(idxM, nM, lane, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
+        for (u32 i = lane; i < nM; i += G::SIZE) idxM[i] = i;
+        G::fence();
+        groupSort<G>(idxM, nM, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
         u32 m1 = 0;
-        for (u32 base = 0; base < nM; base += 64)
+        for (u32 base = 0; base < nM; base += G::SIZE)
         {
             const u32 p = base + lane;
             bool first = false;
@@ -690,13 +806,13 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                 first = p == 0;
                 if (!first) { const RawMatch b = M[idxM[p - 1]]; first = !(sameBinContigStrand(a, b) && mEnd(a) == mEnd(b)); }
             }
-            const u32 slot = wavePush(first, lane, m1);
+            const u32 slot = G::push(first, m1);
             if (first) idxF[slot] = idxM[p];
         }
-        waveFence();
-        waveSort(idxF, m1, lane, [&](u32 a, u32 b) { return lessBegin(M[a], a, M[b], b); });
+        G::fence();
+        groupSort<G>(idxF, m1, [&](u32 a, u32 b) { return lessBegin(M[a], a, M[b], b); });
         u32 m2 = 0;
-        for (u32 base = 0; base < m1; base += 64)
+        for (u32 base = 0; base < m1; base += G::SIZE)
         {
             const u32 q = base + lane;
             bool first = false;
@@ -706,18 +822,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
                 first = q == 0;
                 if (!first) { const RawMatch b = M[idxF[q - 1]]; first = !(sameBinContigStrand(a, b) && a.begin == b.begin); }
             }
-            const u32 slot = wavePush(first, lane, m2);
+            const u32 slot = G::push(first, m2);
             if (first) idxM[slot] = idxF[q];
         }
-        waveFence();
-        waveSort(idxM, m2, lane, [&](u32 a, u32 b) { return lessErrors(M[a], a, M[b], b); });
+        G::fence();
+        groupSort<G>(idxM, m2, [&](u32 a, u32 b) { return lessErrors(M[a], a, M[b], b); });
         const u32 minE = M[idxM[0]].errors;
         const u32 strata = readStrataOf(readLen, A.strataRate);
         u32 cOpt = 0, cSet = 0;
-        for (u32 q = lane; q < m2; q += 64) { const u32 e = M[idxM[q]].errors; cOpt += e == minE; cSet += e <= minE + strata; }
-        const u32 nOpt = waveSum32(cOpt), nSet = waveSum32(cSet);
+        for (u32 q = lane; q < m2; q += G::SIZE) { const u32 e = M[idxM[q]].errors; cOpt += e == minE; cSet += e <= minE + strata; }
+        const u32 nOpt = G::sum(cOpt), nSet = G::sum(cSet);
         const u32 pick = libcxxFirstUniform(nOpt);
-        for (u32 q = lane; q < nSet; q += 64)
+        for (u32 q = lane; q < nSet; q += G::SIZE)
         {
             const RawMatch a = M[idxM[q]];
             OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
@@ -730,7 +846,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeArgs A)
             ro.mapped = a.len != 0; ro.bestCount = nOpt; ro.subCount = nSet - nOpt;
             A.out[read] = ro;
         }
-        waveFence();
+        G::fence();
     }
 }
 
