@@ -3,6 +3,7 @@
 // Layout per the SAM/BAM specification v1: BGZF blocks (gzip members with a "BC" extra field, <= 64 KiB of payload,
 // an empty block as EOF marker) around: magic, header text, reference dictionary, alignment records.
 #pragma once
+#include <charconv>
 #include <zlib.h>
 #include <cstdint>
 #include <cstring>
@@ -131,15 +132,18 @@ inline void bamWriteHeader(BgzfWriter & w, const std::string & text, const std::
 // appends block_size + the record to `out`
 inline void bamEncodeRecord(const AlnRecord & r, std::vector<uint8_t> & out)
 {
+    const uint32_t lSeq = (uint32_t)r.seq.size();
+    const size_t total = 4 + 32 + (r.qname.size() + 1) + (size_t)r.nCigar * 4 + (lSeq + 1) / 2 + lSeq + (r.hasCounts ? 3 * 7 : 0) +
+                         (3 + r.rg.size() + 1) + (r.xa.empty() ? 0 : 3 + r.xa.size() + 1);
     const size_t sizeAt = out.size();
-    out.resize(sizeAt + 4);
-    std::vector<uint8_t> & scratch = out;
-    auto put = [&](const void * p, size_t n) { scratch.insert(scratch.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    out.resize(sizeAt + total);                 // one growth per record, then plain stores
+    uint8_t * w = out.data() + sizeAt;
+    auto put = [&](const void * p, size_t n) { memcpy(w, p, n); w += n; };
     auto put32 = [&](uint32_t v) { put(&v, 4); };
     int64_t refLen = 0;
     for (uint32_t k = 0; k < r.nCigar; ++k) if ((r.cigar[k] & 15) != 1) refLen += r.cigar[k] >> 4;
     const int64_t end = r.pos < 0 ? 0 : (refLen ? r.pos + refLen : r.pos + 1);
-    const uint32_t lSeq = (uint32_t)r.seq.size();
+    put32((uint32_t)(total - 4));
     put32((uint32_t)r.rid); put32((uint32_t)r.pos);
     const uint8_t lName = (uint8_t)(r.qname.size() + 1), mq = (uint8_t)r.mapq;
     const uint16_t bin = bamReg2Bin(r.pos, end), nOp = (uint16_t)r.nCigar, flag = (uint16_t)r.flag;
@@ -147,26 +151,25 @@ inline void bamEncodeRecord(const AlnRecord & r, std::vector<uint8_t> & out)
     put32(lSeq); put32((uint32_t)r.rnext); put32((uint32_t)r.pnext); put32((uint32_t)r.tlen);
     put(r.qname.c_str(), r.qname.size() + 1);
     if (r.nCigar) put(r.cigar, (size_t)r.nCigar * 4);
+    auto code = [](char c) -> uint8_t { switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8; default: return 15; } };
     for (uint32_t i = 0; i < lSeq; i += 2)
     {
-        auto code = [](char c) -> uint8_t { switch (c) { case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': return 8; default: return 15; } };
         uint8_t b = (uint8_t)(code(r.seq[i]) << 4);
         if (i + 1 < lSeq) b |= code(r.seq[i + 1]);
-        put(&b, 1);
+        *w++ = b;
     }
-    for (uint32_t i = 0; i < lSeq; ++i) { uint8_t q = r.qual.size() == lSeq ? (uint8_t)(r.qual[i] - 33) : 0xff; put(&q, 1); }
+    if (r.qual.size() == lSeq) for (uint32_t i = 0; i < lSeq; ++i) *w++ = (uint8_t)(r.qual[i] - 33);
+    else { memset(w, 0xff, lSeq); w += lSeq; }
     auto tagInt = [&](const char * t, uint32_t v) { put(t, 2); put("i", 1); put32(v); };      // typed 'i' like the reference (src/mapper_writer.h:177-191)
     auto tagStr = [&](const char * t, const std::string & v) { put(t, 2); put("Z", 1); put(v.c_str(), v.size() + 1); };
     if (r.hasCounts) { tagInt("NM", r.nm); tagInt("X0", r.x0); tagInt("X1", r.x1); }
     tagStr("RG", r.rg);
     if (!r.xa.empty()) tagStr("XA", r.xa);
-    const uint32_t blockSize = (uint32_t)(out.size() - sizeAt - 4);
-    memcpy(out.data() + sizeAt, &blockSize, 4);
 }
 
 inline void samWriteRecord(std::string & out, const AlnRecord & r, const std::vector<std::string> & names)
 {
-    auto num = [&](long long v) { char b[24]; int n = snprintf(b, sizeof b, "%lld", v); out.append(b, (size_t)n); };
+    auto num = [&](long long v) { char b[24]; const auto r = std::to_chars(b, b + sizeof b, v); out.append(b, (size_t)(r.ptr - b)); };
     out += r.qname; out += '\t'; num(r.flag); out += '\t';
     if (r.rid >= 0) out += names[(size_t)r.rid]; else out += '*';
     out += '\t'; num((long long)r.pos + 1); out += '\t'; num(r.mapq); out += '\t';

@@ -4,6 +4,7 @@
 #include "../../include/dyhip.h"
 #include "host_formats.hpp"
 #include "bam_writer.hpp"
+#include <charconv>
 #include <iostream>
 #include <fstream>
 #include <sstream>
@@ -85,7 +86,7 @@ CliOptions parse(int argc, char ** argv)
     return o;
 }
 
-void appendUint(std::string & s, unsigned long long v) { char buf[24]; int n = snprintf(buf, sizeof buf, "%llu", v); s.append(buf, (size_t)n); }
+void appendUint(std::string & s, unsigned long long v) { char buf[24]; const auto r = std::to_chars(buf, buf + sizeof buf, v); s.append(buf, (size_t)(r.ptr - buf)); }
 
 } // namespace
 
@@ -141,14 +142,17 @@ int main(int argc, char ** argv)
         struct Slot { ReadsBatch batch; dy_reads * reads = nullptr; dy_result * res = nullptr; size_t nPairs = 0; };
         Slot slots[3];
         unsigned long long total = 0, mapped = 0;
-        double mapSeconds = 0;
+        double mapSeconds = 0, parseSeconds = 0, formatSeconds = 0, writeSeconds = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
         auto readInto = [&](Slot & sl) -> bool {
             ReadsBatch & batch = sl.batch;
-            if (!in.next(batch, opt.readsBatch)) return false;
+            const auto p0 = now();
+            if (!in.next(batch, opt.readsBatch, hostThreads)) return false;
             if (in2)
             {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
                 ReadsBatch second;
-                if (in2->next(second, batch.size()) != batch.size()) fail("the two reads files hold different numbers of records");
+                if (in2->next(second, batch.size(), hostThreads) != batch.size()) fail("the two reads files hold different numbers of records");
                 const u64 shift = batch.codes.size();
                 batch.names.insert(batch.names.end(), second.names.begin(), second.names.end());
                 batch.codes.insert(batch.codes.end(), second.codes.begin(), second.codes.end());
@@ -156,6 +160,7 @@ int main(int argc, char ** argv)
                 for (size_t i = 1; i < second.offs.size(); ++i) batch.offs.push_back(second.offs[i] + shift);
             }
             sl.nPairs = batch.size() / 2;
+            parseSeconds += since(p0);
             return true;
         };
         auto formatAndWrite = [&](Slot & sl) {
@@ -168,12 +173,15 @@ int main(int argc, char ** argv)
             const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(hostThreads, batch.size() / 4096 + 1));
             std::vector<std::string> samChunk(T); std::vector<std::vector<uint8_t>> bamChunk(T); std::vector<unsigned long long> mappedChunk(T, 0);
             auto formatChunk = [&](unsigned c) {
-            std::string recText;
             const size_t lo = batch.size() * c / T, hi = batch.size() * (c + 1) / T;
+            if (bam && hi > lo) bamChunk[c].reserve((hi - lo) * (size_t)(2 * (batch.offs[lo + 1] - batch.offs[lo]) + 96));
+            if (!bam && hi > lo) samChunk[c].reserve((hi - lo) * (size_t)(2 * (batch.offs[lo + 1] - batch.offs[lo]) + 96));
+            AlnRecord a;                    // reused: its strings keep their capacity
             for (size_t i = lo; i < hi; ++i)
             {
                 const dy_read_result & r = rr[i];
-                AlnRecord a;
+                a.flag = 0; a.rid = a.pos = -1; a.mapq = 0; a.cigar = nullptr; a.nCigar = 0; a.rnext = a.pnext = -1; a.tlen = 0;
+                a.hasCounts = false; a.nm = a.x0 = a.x1 = 0; a.xa.clear();
                 const std::string & name = batch.names[i];
                 size_t cut = name.find_first_of(" \t/");
                 a.qname.assign(name, 0, cut == std::string::npos ? name.size() : cut);
@@ -231,12 +239,15 @@ int main(int argc, char ** argv)
                 mappedChunk[c] += r.mapped;
             }
             };
+            const auto f0 = now();
             {
                 std::vector<std::thread> pool;
                 for (unsigned c = 1; c < T; ++c) pool.emplace_back(formatChunk, c);
                 formatChunk(0);
                 for (auto & th : pool) th.join();
             }
+            formatSeconds += since(f0);
+            const auto w0 = now();
             for (unsigned c = 0; c < T; ++c)
             {
                 if (bam) bgzf.writeParallel(bamChunk[c].data(), bamChunk[c].size(), hostThreads);
@@ -244,6 +255,7 @@ int main(int argc, char ** argv)
                 mapped += mappedChunk[c];
             }
             total += batch.size();
+            writeSeconds += since(w0);
         };
         auto release = [&](Slot & sl) {          // device objects go back on the thread that drives the context
             if (sl.res) { dy_result_free(sl.res); sl.res = nullptr; }
@@ -287,6 +299,7 @@ int main(int argc, char ** argv)
             dy_map_stats s; dy_map_get_stats(ctx, &s);
             std::cerr << "Loading time:\t\t\t" << std::chrono::duration<double>(t1 - t0).count() << " sec\n"
                       << "Mapping time:\t\t\t" << mapSeconds << " sec\n"
+                      << "Parse / format / write time (overlapped with mapping):\t" << parseSeconds << " / " << formatSeconds << " / " << writeSeconds << " sec\n"
                       << "Total reads:\t\t\t" << total << "\nMapped reads:\t\t\t" << mapped << "\n"
                       << "Last batch: items " << s.items << ", raw matches " << s.raw_matches << ", hard items " << s.hard_items
                       << ", ms ibf/items/search/extend/finalize " << s.ms_ibf << "/" << s.ms_items << "/" << s.ms_search << "/" << s.ms_extend << "/" << s.ms_finalize << "\n";

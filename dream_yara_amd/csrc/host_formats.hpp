@@ -6,6 +6,7 @@
 #include "dy_types.h"
 #include <string>
 #include <vector>
+#include <thread>
 #include <algorithm>
 #include <stdexcept>
 #include <cstdio>
@@ -230,49 +231,85 @@ public:
         else if (map_.size() >= 3 && map_.data()[0] == 'B' && map_.data()[1] == 'Z' && map_.data()[2] == 'h')
             throw IoError("bzip2-compressed input is not supported (no libbz2 on this system)");
     }
-    // appends up to maxReads records; returns the number appended.  Works on byte spans of the mapped file (no temporaries):
-    // one memchr per line, a 256-entry table for the bases.
-    size_t next(ReadsBatch & b, size_t maxReads)
+    // Reads up to maxReads records into b; returns their number.  Two phases over byte spans of the mapped file (no temporaries):
+    // a sequential pass finds the record boundaries (one memchr per line) and the offsets, then `threads` workers convert disjoint
+    // record ranges (256-entry table for the bases) into the pre-sized arrays.
+    size_t next(ReadsBatch & b, size_t maxReads, unsigned threads = 1)
     {
-        static const Dna5Table lut;
         b.clear();
-        size_t n = 0;
-        while (n < maxReads)
+        spans_.clear();
+        size_t bases = 0;
+        while (spans_.size() < maxReads)
         {
             skipBlank();
             if (p_ >= end_) break;
             const char marker = (char)*p_;
             if (marker != '>' && marker != '@') throw IoError("unrecognised reads file format");
+            RecSpan r;
             const u8 * s, * e;
             span(s, e);
-            b.names.emplace_back((const char *)s + 1, (const char *)e);
-            const size_t start = b.codes.size();
-            if (marker == '>')
-            {
-                while (p_ < end_ && *p_ != '>')
-                {
-                    span(s, e);
-                    const size_t at = b.codes.size();
-                    b.codes.resize(at + (size_t)(e - s));
-                    for (size_t i = 0; i < (size_t)(e - s); ++i) b.codes[at + i] = lut.code[s[i]];
-                }
-                b.quals.resize(b.codes.size(), 'I');
+            r.nameS = s + 1; r.nameE = e;
+            r.fasta = marker == '>';
+            r.len = 0;
+            if (r.fasta)
+            {   // the sequence may span several lines: remember the region, count the bases
+                r.seqS = p_;
+                while (p_ < end_ && *p_ != '>') { span(s, e); r.len += (size_t)(e - s); }
+                r.seqE = p_;
+                r.qualS = r.qualE = nullptr;
             }
             else
             {
-                span(s, e);
-                const size_t len = (size_t)(e - s);
-                b.codes.resize(start + len);
-                for (size_t i = 0; i < len; ++i) b.codes[start + i] = lut.code[s[i]];
+                span(s, e); r.seqS = s; r.seqE = e; r.len = (size_t)(e - s);
                 span(s, e);                               // '+'
-                span(s, e);
-                b.quals.resize(start + len, 'I');
-                const size_t ql = std::min(len, (size_t)(e - s));
-                for (size_t i = 0; i < ql; ++i) b.quals[start + i] = (char)(s[i] > 33 + 62 ? 33 + 62 : s[i]);   // Dna5Q keeps 6 quality bits
+                span(s, e); r.qualS = s; r.qualE = e;
             }
-            for (size_t i = start; i < b.codes.size(); ++i) if (b.codes[i] == 4) b.quals[i] = '!';   // N carries no quality
-            b.offs.push_back(b.codes.size());
-            ++n;
+            bases += r.len;
+            b.offs.push_back(bases);
+            spans_.push_back(r);
+        }
+        const size_t n = spans_.size();
+        b.names.resize(n); b.codes.resize(bases); b.quals.resize(bases);
+        auto convert = [&](size_t lo, size_t hi) {
+            static const Dna5Table lut;
+            for (size_t i = lo; i < hi; ++i)
+            {
+                const RecSpan & r = spans_[i];
+                b.names[i].assign((const char *)r.nameS, (const char *)r.nameE);
+                u8 * codes = b.codes.data() + b.offs[i];
+                char * quals = b.quals.data() + b.offs[i];
+                if (r.fasta)
+                {
+                    size_t at = 0;
+                    for (const u8 * q = r.seqS; q < r.seqE;)
+                    {
+                        const u8 * nl = (const u8 *)memchr(q, '\n', (size_t)(r.seqE - q));
+                        const u8 * e = nl ? nl : r.seqE;
+                        const u8 * nextLine = nl ? nl + 1 : r.seqE;
+                        while (e > q && (e[-1] == '\r' || e[-1] == ' ')) --e;
+                        for (const u8 * c = q; c < e; ++c) codes[at++] = lut.code[*c];
+                        q = nextLine;
+                    }
+                    for (size_t k = 0; k < r.len; ++k) quals[k] = codes[k] == 4 ? '!' : 'I';
+                }
+                else
+                {
+                    const size_t ql = std::min(r.len, (size_t)(r.qualE - r.qualS));
+                    for (size_t k = 0; k < r.len; ++k) codes[k] = lut.code[r.seqS[k]];
+                    for (size_t k = 0; k < ql; ++k) quals[k] = (char)(r.qualS[k] > 33 + 62 ? 33 + 62 : r.qualS[k]);   // Dna5Q keeps 6 quality bits
+                    for (size_t k = ql; k < r.len; ++k) quals[k] = 'I';
+                    for (size_t k = 0; k < r.len; ++k) if (codes[k] == 4) quals[k] = '!';                               // N carries no quality
+                }
+            }
+        };
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 8192 + 1));
+        if (T <= 1) convert(0, n);
+        else
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; ++t) pool.emplace_back(convert, n * t / T, n * (t + 1) / T);
+            convert(0, n / T);
+            for (auto & th : pool) th.join();
         }
         return n;
     }
@@ -288,6 +325,8 @@ private:
         p_ = nl ? nl + 1 : end_;
         while (e > s && (e[-1] == '\r' || e[-1] == ' ')) --e;
     }
+    struct RecSpan { const u8 * nameS, * nameE, * seqS, * seqE, * qualS, * qualE; size_t len; bool fasta; };
+    std::vector<RecSpan> spans_;
     MappedFile map_;
     std::vector<u8> inflated_;
     const u8 * p_; const u8 * end_;

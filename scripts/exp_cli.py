@@ -34,4 +34,4 @@ for out in ("out.sam", "out.bam"):
     t0 = time.time()
     subprocess.check_call([exe, "-fi", fpath, idx_dir, fq, "-o", os.path.join(work, out), "-e", "3", "-rb", "1000000", "-v"], stderr=open(os.path.join(work, "cli.err"), "w"))
     dt = time.time() - t0
-    print(out, "%.1f s total" % dt, "%.2f M reads/s" % (n / dt / 1e6), "| stderr:", " / ".join(l.strip() for l in open(os.path.join(work, "cli.err")) if "time" in l))
+    print(out, "%.1f s total" % dt, "%.2f M reads/s" % (n / dt / 1e6), "| stderr:", " / ".join(l.strip() for l in open(os.path.join(work, "cli.err")) if "time" in l or "Parse" in l))

@@ -1,5 +1,5 @@
 // Test harness for the host-side I/O of dream_yara_mapper (no GPU): built and driven by tests/test_host_io.py.
-//   host_io_harness parse <reads file> <max per batch>      -> one line per read: name<TAB>ACGTN string<TAB>qualities
+//   host_io_harness parse <reads file> <max per batch> [threads] -> one line per read: name<TAB>ACGTN string<TAB>qualities
 //   host_io_harness write <out.sam> <out.bam> <n> <threads> -> the same n synthetic records as SAM text and as BGZF BAM
 #include "../../dream_yara_amd/csrc/host_formats.hpp"
 #include "../../dream_yara_amd/csrc/bam_writer.hpp"
@@ -14,13 +14,14 @@ int main(int argc, char ** argv)
     try
     {
         const std::string mode = argc > 1 ? argv[1] : "";
-        if (mode == "parse" && argc == 4)
+        if (mode == "parse" && (argc == 4 || argc == 5))
         {
             ReadsFile in(argv[2]);
             ReadsBatch b;
             const size_t per = std::stoul(argv[3]);
+            const unsigned threads = argc == 5 ? (unsigned)std::stoul(argv[4]) : 1;
             size_t batches = 0;
-            while (in.next(b, per))
+            while (in.next(b, per, threads))
             {
                 ++batches;
                 for (size_t i = 0; i < b.size(); ++i)

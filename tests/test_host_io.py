@@ -39,6 +39,23 @@ def test_reads_parser_handles_fasta_fastq_gzip_and_odd_lines(harness, tmp_path):
     assert subprocess.call([harness, "parse", str(bad), "10"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
 
 
+def test_threaded_parse_equals_sequential_parse(harness, tmp_path):
+    import random
+    rnd = random.Random(5)
+    fq, fa = tmp_path / "big.fq", tmp_path / "big.fa"
+    with open(fq, "w") as f, open(fa, "w") as g:
+        for i in range(40000):
+            L = rnd.randint(1, 180)
+            seq = "".join(rnd.choice("ACGTN" if rnd.random() < 0.02 else "ACGT") for _ in range(L))
+            f.write("@read_%d some description\n%s\n+\n%s\n" % (i, seq, "".join(chr(rnd.randint(33, 126)) for _ in range(L))))
+            g.write(">read_%d\n%s\n" % (i, "\n".join(seq[k:k + 60] for k in range(0, L, 60))))
+    for path in (fq, fa):
+        one = subprocess.check_output([harness, "parse", str(path), "1000000", "1"])
+        assert one.count(b"\n") == 40000
+        assert subprocess.check_output([harness, "parse", str(path), "1000000", "6"]) == one
+        assert subprocess.check_output([harness, "parse", str(path), "17000", "3"]) == one      # several batches
+
+
 @pytest.mark.parametrize("n,threads", [(0, 1), (50, 1), (4000, 4)])
 def test_bam_stream_decodes_to_the_sam_text(harness, tmp_path, n, threads):
     sam, bam = str(tmp_path / "o.sam"), str(tmp_path / "o.bam")
