@@ -851,7 +851,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
 }
 
 // Fast path, one thread per read: a read without matches is unmapped; a read whose only match is ungapped needs no
-// sorting, no alignment and has X0 = 1, X1 = 0.  Everything else is queued for k_finalize.
+// sorting, no alignment and has X0 = 1, X1 = 0.  Everything else is queued for k_finalize_t.
 __device__ __forceinline__ void writeSingleMatch(const FinalizeArgs & A, u32 read, ReadOut & ro, const RawMatch & a)
 {
     OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(64) void k_align_single(FinalizeArgs A, const u32 *
     }
 }
 
-// Reads with 2..SMALL_T matches, one thread each: the same child/main aggregation as k_finalize with insertion sorts over
+// Reads with 2..SMALL_T matches, one thread each: the same child/main aggregation as k_finalize_t with insertion sorts over
 // a handful of entries in private memory (the wavefront version spends ~10^4 instructions per read on these).
 enum { SMALL_T = 4 };
 template <typename TLess>

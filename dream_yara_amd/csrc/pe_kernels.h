@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void k_pe_finalize(FinalizeArgs A, PeView V, c
                 p0 = p1;
             }
         }
-        // ---- main mapper: aggregateMatches + rankMatches2 over the union (same as k_finalize)
+        // ---- main mapper: aggregateMatches + rankMatches2 over the union (same as k_finalize_t)
         for (u32 i = lane; i < nM; i += 64) idxM[i] = i;
         waveFence();
         waveSort(idxM, nM, lane, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
