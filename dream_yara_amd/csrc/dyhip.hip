@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <cstddef>
+#include <thread>
 
 #include "../../include/dyhip.h"
 #include "dy_types.h"
@@ -79,6 +81,7 @@ struct PinnedBuf
         cap = want;
     }
     template <typename T> T * as() const { return (T *)p; }
+    void moveTo(PinnedBuf & o) { if (o.p) (void)hipHostFree(o.p); o.p = p; o.cap = cap; p = nullptr; cap = 0; }
 };
 
 int deviceCount()
@@ -105,7 +108,8 @@ struct dy_ctx
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
     size_t poolCap = 0;
-    PinnedBuf hostOut, hostSet, hostCigars;     // staging of dy_result_fetch
+    PinnedBuf sparePinned[9];           // host arrays of fetched results, handed back by dy_result_free (hipHostMalloc costs milliseconds)
+    DevBuf packCntSet, packCntOps, packOffSet, packOffOps, packReads, packSet, packOps;     // dy_result_fetch: dense copies made on the device
     DevBuf spare[12];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
@@ -128,6 +132,23 @@ static void giveBuffer(dy_ctx * ctx, DevBuf & d)
     for (int i = 0; i < 12; ++i) if (!ctx->spare[i].p) { slot = i; break; }
     if (slot < 0) { slot = 0; for (int i = 1; i < 12; ++i) if (ctx->spare[i].cap < ctx->spare[slot].cap) slot = i; if (ctx->spare[slot].cap >= d.cap) return; }
     d.moveTo(ctx->spare[slot]);
+}
+
+static void takePinned(dy_ctx * ctx, PinnedBuf & d, size_t bytes)
+{
+    int best = -1;
+    for (int i = 0; i < 9; ++i)
+        if (ctx->sparePinned[i].p && ctx->sparePinned[i].cap >= bytes && (best < 0 || ctx->sparePinned[i].cap < ctx->sparePinned[best].cap)) best = i;
+    if (best >= 0) ctx->sparePinned[best].moveTo(d);
+    else d.reserve(bytes);
+}
+static void givePinned(dy_ctx * ctx, PinnedBuf & d)
+{
+    if (!d.p) return;
+    int slot = -1;
+    for (int i = 0; i < 9; ++i) if (!ctx->sparePinned[i].p) { slot = i; break; }
+    if (slot < 0) { slot = 0; for (int i = 1; i < 9; ++i) if (ctx->sparePinned[i].cap < ctx->sparePinned[slot].cap) slot = i; if (ctx->sparePinned[slot].cap >= d.cap) return; }
+    d.moveTo(ctx->sparePinned[slot]);
 }
 
 struct dy_ibf
@@ -182,10 +203,37 @@ struct dy_result
     std::shared_ptr<const std::vector<u32>> readLens;
     DevBuf out, outSet, cigars;
     bool fetched = false;
-    std::vector<dy_read_result> reads;
-    std::vector<dy_match> matches;
-    std::vector<u32> cigarOps;
+    PinnedBuf reads, matches, cigarOps;      // dy_read_result[nReads], dy_match[nMatches], u32[nOps] after dy_result_fetch
+    size_t nMatches = 0, nOps = 0;
 };
+
+// dy_result_fetch, device side: the per-read records with dense matchesSet / CIGAR offsets (the finalize kernels write both at
+// capacity-sized strides), so that only what the host arrays hold crosses PCIe
+__global__ void k_result_counts(const ReadOut * __restrict__ out, u32 n, u32 * __restrict__ cntSet, u32 * __restrict__ cntOps)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    cntSet[i] = i < n ? out[i].bestCount + out[i].subCount : 0;
+    cntOps[i] = i < n && out[i].mapped ? out[i].cigarLen : 0;
+}
+__global__ void k_result_pack(const ReadOut * __restrict__ out, const OutMatch * __restrict__ outSet, const u32 * __restrict__ cigars, u32 n,
+                              const u32 * __restrict__ offSet, const u32 * __restrict__ offOps,
+                              ReadOut * __restrict__ packReads, OutMatch * __restrict__ packSet, u32 * __restrict__ packOps)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ReadOut o = out[i];
+    const u32 nset = o.bestCount + o.subCount, nops = o.mapped ? o.cigarLen : 0;
+    const u32 s = offSet[i], c = offOps[i];
+    for (u32 k = 0; k < nset; ++k) packSet[s + k] = outSet[(size_t)o.setBegin + k];
+    for (u32 k = 0; k < nops; ++k) packOps[c + k] = cigars[(size_t)o.cigarBegin + k];
+    o.setBegin = s; o.cigarBegin = c; o.cigarLen = nops;
+    packReads[i] = o;
+}
+static_assert(sizeof(ReadOut) == sizeof(dy_read_result) && sizeof(OutMatch) == sizeof(dy_match), "device mirrors of the ABI records");
+static_assert(offsetof(ReadOut, mapq) == offsetof(dy_read_result, mapq) && offsetof(ReadOut, setBegin) == offsetof(dy_read_result, set_begin) &&
+              offsetof(ReadOut, cigarBegin) == offsetof(dy_read_result, cigar_begin) && offsetof(ReadOut, pairProb) == offsetof(dy_read_result, pair_prob) &&
+              offsetof(ReadOut, errors) == offsetof(dy_read_result, primary.errors), "device mirrors of the ABI records");
 
 template <typename T> static void upload(DevBuf & d, const std::vector<T> & h)
 {
@@ -1015,54 +1063,65 @@ int dy_result_fetch(dy_result * r)
         if (r->fetched) return;
         dy_ctx * ctx = r->ctx;
         HIP_CHECK(hipSetDevice(ctx->device));
-        const size_t nCigarWords = (size_t)r->nReads * r->cigarStride;
-        ctx->hostOut.reserve((size_t)r->nReads * sizeof(ReadOut) + 64); ctx->hostSet.reserve(r->setCap * sizeof(OutMatch) + 64);
-        ctx->hostCigars.reserve(nCigarWords * 4 + 64);
-        const ReadOut * ro = ctx->hostOut.as<ReadOut>(); const OutMatch * os = ctx->hostSet.as<OutMatch>(); const u32 * cg = ctx->hostCigars.as<u32>();
-        if (r->nReads) HIP_CHECK(hipMemcpyAsync(ctx->hostOut.p, r->out.p, (size_t)r->nReads * sizeof(ReadOut), hipMemcpyDeviceToHost, ctx->stream));
-        if (r->setCap) HIP_CHECK(hipMemcpyAsync(ctx->hostSet.p, r->outSet.p, r->setCap * sizeof(OutMatch), hipMemcpyDeviceToHost, ctx->stream));
-        if (nCigarWords) HIP_CHECK(hipMemcpyAsync(ctx->hostCigars.p, r->cigars.p, nCigarWords * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        r->reads.resize(r->nReads);
-        r->matches.clear(); r->cigarOps.clear();
-        size_t nMatches = 0, nOps = 0;
-        for (u32 i = 0; i < r->nReads; ++i) { nMatches += ro[i].bestCount + ro[i].subCount; nOps += ro[i].mapped ? ro[i].cigarLen : 0; }
-        r->matches.reserve(nMatches); r->cigarOps.reserve(nOps);
-        // MAPQ is a pure function of (errors, read length, best, sub): a small memo covers nearly every read (3 pow + 1 log10 each otherwise)
-        enum { MEMO_E = 16, MEMO_C = 8 };
-        u32 memoLen = 0; int memo[MEMO_E][MEMO_C][MEMO_C];
-        for (auto & a : memo) for (auto & b : a) for (auto & c : b) c = -1;
-        for (u32 i = 0; i < r->nReads; ++i)
-        {
-            const ReadOut & o = ro[i];
-            dy_read_result & d = r->reads[i];
-            d.primary.contig = o.contig; d.primary.begin = o.begin; d.primary.length = o.length; d.primary.errors = o.errors; d.primary.is_rev = o.isRev;
-            d.mapped = o.mapped; d.best_count = o.bestCount; d.sub_count = o.subCount;
-            d.paired = o.paired; d.reserved = 0; d.pair_prob = o.pairProb;
-            if (!o.mapped) d.mapq = 0;
-            else if (o.paired) d.mapq = (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(o.pairProb, 0.9999999)));
-            else
+        const u32 n = r->nReads;
+        hipStream_t st = ctx->stream;
+        // dense offsets of every read's matchesSet and CIGAR, then one packing pass on the device
+        ctx->packCntSet.reserve((size_t)(n + 1) * 4); ctx->packCntOps.reserve((size_t)(n + 1) * 4);
+        ctx->packOffSet.reserve((size_t)(n + 1) * 4); ctx->packOffOps.reserve((size_t)(n + 1) * 4);
+        hipLaunchKernelGGL(k_result_counts, dim3(n / 256 + 1), dim3(256), 0, st, r->out.as<ReadOut>(), n, ctx->packCntSet.as<u32>(), ctx->packCntOps.as<u32>());
+        exclusiveSum(ctx, ctx->packCntSet.as<u32>(), ctx->packOffSet.as<u32>(), (size_t)n + 1);
+        exclusiveSum(ctx, ctx->packCntOps.as<u32>(), ctx->packOffOps.as<u32>(), (size_t)n + 1);
+        u32 totals[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(&totals[0], ctx->packOffSet.as<u32>() + n, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&totals[1], ctx->packOffOps.as<u32>() + n, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        r->nMatches = totals[0]; r->nOps = totals[1];
+        ctx->packReads.reserve((size_t)n * sizeof(ReadOut) + 64); ctx->packSet.reserve(r->nMatches * sizeof(OutMatch) + 64); ctx->packOps.reserve(r->nOps * 4 + 64);
+        if (n)
+            hipLaunchKernelGGL(k_result_pack, dim3((n + 255) / 256), dim3(256), 0, st, r->out.as<ReadOut>(), r->outSet.as<OutMatch>(), r->cigars.as<u32>(), n,
+                               ctx->packOffSet.as<u32>(), ctx->packOffOps.as<u32>(), ctx->packReads.as<ReadOut>(), ctx->packSet.as<OutMatch>(), ctx->packOps.as<u32>());
+        takePinned(ctx, r->reads, (size_t)n * sizeof(dy_read_result) + 64);
+        takePinned(ctx, r->matches, r->nMatches * sizeof(dy_match) + 64);
+        takePinned(ctx, r->cigarOps, r->nOps * 4 + 64);
+        if (n) HIP_CHECK(hipMemcpyAsync(r->reads.p, ctx->packReads.p, (size_t)n * sizeof(ReadOut), hipMemcpyDeviceToHost, st));
+        if (r->nMatches) HIP_CHECK(hipMemcpyAsync(r->matches.p, ctx->packSet.p, r->nMatches * sizeof(OutMatch), hipMemcpyDeviceToHost, st));
+        if (r->nOps) HIP_CHECK(hipMemcpyAsync(r->cigarOps.p, ctx->packOps.p, r->nOps * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        // MAPQ (fp64, host libm: reference src/mapper_writer.h:221-225) is a pure function of (errors, read length, best, sub): a small
+        // memo covers nearly every read (3 pow + 1 log10 each otherwise); read ranges go to a few threads
+        dy_read_result * reads = r->reads.as<dy_read_result>();
+        const std::vector<u32> & lens = *r->readLens;
+        auto fillMapq = [&](u32 lo, u32 hi) {
+            enum { MEMO_E = 16, MEMO_C = 8 };
+            u32 memoLen = 0; int memo[MEMO_E][MEMO_C][MEMO_C];
+            for (auto & a : memo) for (auto & b : a) for (auto & c : b) c = -1;
+            for (u32 i = lo; i < hi; ++i)
             {
-                const u32 len = (*r->readLens)[i];
-                if (len != memoLen) { memoLen = len; for (auto & a : memo) for (auto & b : a) for (auto & c : b) c = -1; }
-                if (o.errors < MEMO_E && o.bestCount < MEMO_C && o.subCount < MEMO_C)
+                dy_read_result & d = reads[i];
+                if (!d.mapped) d.mapq = 0;
+                else if (d.paired) d.mapq = (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(d.pair_prob, 0.9999999)));
+                else
                 {
-                    int & m = memo[o.errors][o.bestCount][o.subCount];
-                    if (m < 0) m = (int)mapqOf(o.errors, len, o.bestCount, o.subCount);
-                    d.mapq = (unsigned)m;
+                    const u32 len = lens[i];
+                    if (len != memoLen) { memoLen = len; for (auto & a : memo) for (auto & b : a) for (auto & c : b) c = -1; }
+                    if (d.primary.errors < MEMO_E && d.best_count < MEMO_C && d.sub_count < MEMO_C)
+                    {
+                        int & m = memo[d.primary.errors][d.best_count][d.sub_count];
+                        if (m < 0) m = (int)mapqOf(d.primary.errors, len, d.best_count, d.sub_count);
+                        d.mapq = (unsigned)m;
+                    }
+                    else d.mapq = mapqOf(d.primary.errors, len, d.best_count, d.sub_count);
                 }
-                else d.mapq = mapqOf(o.errors, len, o.bestCount, o.subCount);
             }
-            d.set_begin = (u32)r->matches.size();
-            u32 nset = o.bestCount + o.subCount;
-            for (u32 k = 0; k < nset; ++k)
-            {
-                const OutMatch & m = os[(size_t)o.setBegin + k];
-                dy_match dm; dm.contig = m.contig; dm.begin = m.begin; dm.length = m.length; dm.errors = m.errors; dm.is_rev = m.isRev;
-                r->matches.push_back(dm);
-            }
-            d.cigar_begin = (u32)r->cigarOps.size(); d.cigar_len = o.mapped ? o.cigarLen : 0;
-            for (u32 k = 0; k < d.cigar_len; ++k) r->cigarOps.push_back(cg[(size_t)o.cigarBegin + k]);
+        };
+        const u32 T = std::min<u32>(4, n / 65536 + 1);
+        if (T <= 1) fillMapq(0, n);
+        else
+        {
+            std::vector<std::thread> pool;
+            for (u32 t = 1; t < T; ++t) pool.emplace_back(fillMapq, (u32)((u64)n * t / T), (u32)((u64)n * (t + 1) / T));
+            fillMapq(0, (u32)((u64)n / T));
+            for (auto & th : pool) th.join();
         }
         r->fetched = true;
     });
@@ -1077,15 +1136,16 @@ int dy_map_reads(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_
     return rc;
 }
 
-const dy_read_result * dy_result_reads(const dy_result * r) { return (r && r->fetched) ? r->reads.data() : nullptr; }
-const dy_match * dy_result_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.data() : nullptr; }
-uint64_t dy_result_n_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.size() : 0; }
-const uint32_t * dy_result_cigars(const dy_result * r) { return (r && r->fetched) ? r->cigarOps.data() : nullptr; }
+const dy_read_result * dy_result_reads(const dy_result * r) { return (r && r->fetched) ? r->reads.as<dy_read_result>() : nullptr; }
+const dy_match * dy_result_matches(const dy_result * r) { return (r && r->fetched) ? r->matches.as<dy_match>() : nullptr; }
+uint64_t dy_result_n_matches(const dy_result * r) { return (r && r->fetched) ? r->nMatches : 0; }
+const uint32_t * dy_result_cigars(const dy_result * r) { return (r && r->fetched) ? r->cigarOps.as<u32>() : nullptr; }
 void dy_result_free(dy_result * r)
 {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     giveBuffer(r->ctx, r->out); giveBuffer(r->ctx, r->outSet); giveBuffer(r->ctx, r->cigars);
+    givePinned(r->ctx, r->reads); givePinned(r->ctx, r->matches); givePinned(r->ctx, r->cigarOps);
     delete r;
 }
 
