@@ -103,7 +103,7 @@ struct dy_ctx
     dy_map_stats stats = {};
     bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
-    DevBuf peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
+    DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
@@ -453,7 +453,14 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             hipLaunchKernelGGL(k_pe_child_simple, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
             hipLaunchKernelGGL(k_pe_child, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
             hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(1024), 0, st, V);
-            if (nItems) hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V);
+            if (nItems)
+            {   // pairs whose mates have many unique matches (repeats) are paired by a wavefront each
+                const u32 heavyMin = getenv("DY_PE_HEAVY_MIN") ? (u32)atoi(getenv("DY_PE_HEAVY_MIN")) : 256u;
+                ctx->peHeavy.reserve((size_t)nItems * 4 + 64);
+                u32 * heavyCount = ctx->counters.as<u32>() + 11;
+                hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V, heavyMin, ctx->peHeavy.as<u32>(), heavyCount);
+                hipLaunchKernelGGL(k_pe_pair_heavy, dim3(1024), dim3(256), 0, st, fa, V, ctx->peHeavy.as<u32>(), heavyCount);
+            }
             if (p->verify_matches && nItems)
             {
                 std::vector<PeLibrary> hostLib(nBins);

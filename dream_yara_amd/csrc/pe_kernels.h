@@ -412,29 +412,35 @@ __device__ inline void peFindProperMates(const RawMatch * mates, u32 nMates, con
     if (first > last) { first = 0; last = 0; }
 }
 
-// findPrimaryMatch (reference src/bits_matches.h:972-1041)
+// findPrimaryMatch (reference src/bits_matches.h:972-1041): weight of first-mate match f summed over its proper mates, in the mates' order
+__device__ inline double pePairWeight(const RawMatch & f, const RawMatch * sm, u32 nS, double firstOpt, double secondOpt, u32 secondOptCount, u32 secondSubCount,
+                                      u32 firstLen, u32 secondLen, const u64 * limits, u32 mean, u32 stdDev)
+{
+    double w = 0.0;
+    u64 optImproper = secondOptCount, subImproper = secondSubCount;
+    u32 first, last;
+    peFindProperMates(sm, nS, f, secondLen, (u32)(limits[f.contig + 1] - limits[f.contig]), mean, stdDev, first, last);
+    for (u32 k = first; k < last; ++k)
+    {
+        const RawMatch s = sm[k];
+        const double secondErrorRate = (double)((float)s.errors / (float)secondLen);
+        w += peMatchWeight(secondErrorRate, secondOpt) * peLibraryProb(f, s, mean, stdDev);
+        if (secondErrorRate == secondOpt) --optImproper;
+        else if (secondErrorRate == secondOpt + 0.01) --subImproper;
+    }
+    w += ((double)optImproper * peMatchWeight(secondOpt, secondOpt) + (double)subImproper * peMatchWeight(secondOpt + 0.01, secondOpt) + peResidualWeight(secondOpt)) * 0.0009;
+    const double firstErrorRate = (double)((float)f.errors / (float)firstLen);
+    w *= peMatchWeight(firstErrorRate, firstOpt);
+    return w;
+}
+
 __device__ inline bool peFindPrimary(const RawMatch * fm, u32 nF, const RawMatch * sm, u32 nS, double firstOpt, double secondOpt, u32 secondOptCount, u32 secondSubCount,
                                      u32 firstLen, u32 secondLen, const u64 * limits, u32 mean, u32 stdDev, u32 & bestIdx, double & prob)
 {
     double sum = 0.0, best = 0.0; bool found = false;
     for (u32 i = 0; i < nF; ++i)
     {
-        const RawMatch f = fm[i];
-        double w = 0.0;
-        u64 optImproper = secondOptCount, subImproper = secondSubCount;
-        u32 first, last;
-        peFindProperMates(sm, nS, f, secondLen, (u32)(limits[f.contig + 1] - limits[f.contig]), mean, stdDev, first, last);
-        for (u32 k = first; k < last; ++k)
-        {
-            const RawMatch s = sm[k];
-            const double secondErrorRate = (double)((float)s.errors / (float)secondLen);
-            w += peMatchWeight(secondErrorRate, secondOpt) * peLibraryProb(f, s, mean, stdDev);
-            if (secondErrorRate == secondOpt) --optImproper;
-            else if (secondErrorRate == secondOpt + 0.01) --subImproper;
-        }
-        w += ((double)optImproper * peMatchWeight(secondOpt, secondOpt) + (double)subImproper * peMatchWeight(secondOpt + 0.01, secondOpt) + peResidualWeight(secondOpt)) * 0.0009;
-        const double firstErrorRate = (double)((float)f.errors / (float)firstLen);
-        w *= peMatchWeight(firstErrorRate, firstOpt);
+        const double w = pePairWeight(fm[i], sm, nS, firstOpt, secondOpt, secondOptCount, secondSubCount, firstLen, secondLen, limits, mean, stdDev);
         if (w > best) { best = w; bestIdx = i; found = true; }
         sum += w;
     }
@@ -442,8 +448,31 @@ __device__ inline bool peFindPrimary(const RawMatch * fm, u32 nF, const RawMatch
     return found;
 }
 
-// ---- stage 3: one thread per pair of a bin -------------------------------------------------------------------------
-__global__ void k_pe_pair(FinalizeArgs A, PeView V)
+// Same for one wavefront: the weights of 64 first-mate matches are computed side by side, then folded in index order (the sum and
+// the first maximum are order-dependent in fp64, so the fold is sequential); every lane ends with the same result.
+__device__ inline bool peFindPrimaryWave(const RawMatch * fm, u32 nF, const RawMatch * sm, u32 nS, double firstOpt, double secondOpt, u32 secondOptCount, u32 secondSubCount,
+                                         u32 firstLen, u32 secondLen, const u64 * limits, u32 mean, u32 stdDev, u32 & bestIdx, double & prob, u32 lane)
+{
+    double sum = 0.0, best = 0.0; bool found = false;
+    for (u32 base = 0; base < nF; base += 64)
+    {
+        const u32 i = base + lane;
+        double w = 0.0;
+        if (i < nF) w = pePairWeight(fm[i], sm, nS, firstOpt, secondOpt, secondOptCount, secondSubCount, firstLen, secondLen, limits, mean, stdDev);
+        const u32 cnt = nF - base < 64 ? nF - base : 64;
+        for (u32 l = 0; l < cnt; ++l)
+        {
+            const double wl = __shfl(w, (int)l, 64);
+            if (wl > best) { best = wl; bestIdx = base + l; found = true; }
+            sum += wl;
+        }
+    }
+    prob = best / sum;
+    return found;
+}
+
+// ---- stage 3: one thread per pair of a bin; pairs with many unique matches go to a list for k_pe_pair_heavy -------------------------
+__global__ void k_pe_pair(FinalizeArgs A, PeView V, u32 heavyMin, u32 * __restrict__ heavyList, u32 * __restrict__ heavyCount)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= V.nItems) return;
@@ -455,6 +484,7 @@ __global__ void k_pe_pair(FinalizeArgs A, PeView V)
     PeItem & a = V.items[t];
     PeItem & b = V.items[t + Pc];
     if (!a.nU2 || !b.nU2) return;
+    if (a.nU2 + b.nU2 > heavyMin) { heavyList[atomicAdd(heavyCount, 1u)] = t; return; }
     const u32 ra = V.itemRead[t], rb = V.itemRead[t + Pc];
     const u32 aLen = (u32)(A.readOffs[ra + 1] - A.readOffs[ra]), bLen = (u32)(A.readOffs[rb + 1] - A.readOffs[rb]);
     const double aOpt = (double)((float)a.minErr / (float)aLen), bOpt = (double)((float)b.minErr / (float)bLen);
@@ -464,6 +494,31 @@ __global__ void k_pe_pair(FinalizeArgs A, PeView V)
     const bool fb = peFindPrimary(V.u2 + b.u2Off, b.nU2, V.u2 + a.u2Off, a.nU2, bOpt, aOpt, a.nOpt, a.nSet - a.nOpt, bLen, aLen, limits, L.length, L.dev, ib, pb);
     if (!fa || !fb) return;
     a.primary = ia; b.primary = ib; a.prob = pa; b.prob = pb; a.paired = 1; b.paired = 1;
+}
+
+// one wavefront per listed pair (repeat-rich mates: thousands of unique matches each)
+__global__ __launch_bounds__(256) void k_pe_pair_heavy(FinalizeArgs A, PeView V, const u32 * __restrict__ heavyList, const u32 * __restrict__ heavyCount)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nWaves = (gridDim.x * blockDim.x) >> 6;
+    const u32 nList = *heavyCount;
+    for (u32 li = gwave; li < nList; li += nWaves)
+    {
+        const u32 t = heavyList[li];
+        const u32 bin = V.itemBin[t];
+        const u32 b0 = V.binStart[bin], Pc = (V.binStart[bin + 1] - b0) / 2;
+        const PeLibrary L = V.lib[bin];
+        PeItem & a = V.items[t];
+        PeItem & b = V.items[t + Pc];
+        const u32 ra = V.itemRead[t], rb = V.itemRead[t + Pc];
+        const u32 aLen = (u32)(A.readOffs[ra + 1] - A.readOffs[ra]), bLen = (u32)(A.readOffs[rb + 1] - A.readOffs[rb]);
+        const double aOpt = (double)((float)a.minErr / (float)aLen), bOpt = (double)((float)b.minErr / (float)bLen);
+        const u64 * limits = A.limits + A.bins[bin].limOff;
+        u32 ia = 0, ib = 0; double pa = 0.0, pb = 0.0;
+        const bool fa = peFindPrimaryWave(V.u2 + a.u2Off, a.nU2, V.u2 + b.u2Off, b.nU2, aOpt, bOpt, b.nOpt, b.nSet - b.nOpt, aLen, bLen, limits, L.length, L.dev, ia, pa, lane);
+        const bool fb = peFindPrimaryWave(V.u2 + b.u2Off, b.nU2, V.u2 + a.u2Off, a.nU2, bOpt, aOpt, a.nOpt, a.nSet - a.nOpt, bLen, aLen, limits, L.length, L.dev, ib, pb, lane);
+        if (fa && fb && lane == 0) { a.primary = ia; b.primary = ib; a.prob = pa; b.prob = pb; a.paired = 1; b.paired = 1; }
+    }
 }
 
 // ---- stage 4: mate rescue -------------------------------------------------------------------------------------------

@@ -13,13 +13,15 @@ idx_dir = "/tmp/dy_rep_idx"; os.makedirs(idx_dir, exist_ok=True)
 for b, g in enumerate(genomes):
     ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+PAIRED = len(sys.argv) > 2 and sys.argv[2] == "paired"      # first half / second half of the batch as mates (unrelated: exercises the path only)
 codes, offs = _sample_reads(rng, genomes, fam, N, 100, 3)
 ctx = dy.Context(0); idx = dy.Index(ctx, idx_dir, n_bins); rd = dy.Reads(ctx, codes, offs)
 params = dy.default_params(error_rate=np.float32(0.03)); params.use_filter = 0
+if PAIRED: params.paired = 1
 for it in range(3):
     t0 = time.perf_counter()
     res = dy.map_reads(ctx, idx, rd, params, asynchronous=True); ctx.sync()
     dt = time.perf_counter() - t0
     st = ctx.stats(); res.close()
 print("reads", N + 2, "items", st["items"], "hard", st["hard_items"], "raw matches", st["raw_matches"], "ms total %.1f" % (1e3 * dt),
-      {k: round(st[k], 2) for k in ("ms_items", "ms_search", "ms_extend", "ms_finalize")}, "pool retries", st["pool_retries"])
+      {k: round(st[k], 2) for k in ("ms_items", "ms_search", "ms_extend", "ms_finalize")}, "pool retries", st["pool_retries"], "paired" if PAIRED else "single-end")
