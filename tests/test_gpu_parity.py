@@ -608,6 +608,39 @@ def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
     assert sam_records(sam) == sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.tag.t1.sam"))
 
 
+@pytest.mark.gpu
+def test_paired_end_on_repeat_families_matches_oracle(dy, ctx, ob, tmp_path):
+    """Mates from planted repeat families: hundreds of unique matches per mate and bin -> the wavefront pairing path
+    (k_pe_pair_heavy), the re-seeded extension and the large per-read aggregation, all against the oracle."""
+    from dream_yara_amd import synth
+    rng = np.random.default_rng(4242)
+    n_bins = 4
+    genomes, _ = _repeat_genomes(rng, n_bins, 60000)
+    genomes[1] = np.concatenate([genomes[1][:1000], genomes[1][33000:]])        # without the 32 kbp poly-A run (pairing there is quadratic on any machine)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    codes, offs, _ = synth.simulate_pairs(genomes, 1500, 100, seed=11, insert_mean=330.0, insert_sd=25.0)
+    er, sr = np.float32(0.03), np.float32(0.0)
+    idx = dy.Index(ctx, idx_dir, n_bins)
+    reads = dy.Reads(ctx, codes, offs)
+    params = dy.default_params(error_rate=er, strata_rate=sr, paired=1)
+    params.use_filter = 0
+    res = dy.map_reads(ctx, idx, reads, params)
+    dev = (res.reads(), res.matches(), res.cigars())
+    stats = ctx.stats()
+    res.close(); reads.close(); idx.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins)
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, None, codes, offs, er, sr, paired=True)
+    oidx.close()
+    assert stats["raw_matches"] == ostats["raw_matches"]
+    assert stats["hard_items"] > 50
+    assert np.array_equal(dev[0]["paired"], o_reads["paired"])
+    assert np.array_equal(dev[0]["pair_prob"], o_reads["pair_prob"])
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
+    assert (o_reads["best_count"] > 100).sum() > 100           # the repeat reads really carry hundreds of co-optimal locations
+
+
 @pytest.mark.parametrize("extra", [[], ["-ll", "320", "-ld", "30", "-s", "2"], ["-ni"]])
 def test_cli_paired_end_sam_equals_oracle_cli(product_build, oracle_build, ob, tmp_path, extra):
     """Two reads files -> paired SAM (flags, RNEXT/PNEXT/TLEN, pair MAPQ): the product CLI's text equals the oracle CLI's.
