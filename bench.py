@@ -207,7 +207,7 @@ def main():
         # HBM traffic of K1 per launch from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes;
         # narrow gathers are accounted at 64 B per request, calibrated on scripts/ubench_gather.hip: profiles/r01_fetch_size_calibration.json)
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01m_pmc_config2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01n_pmc_config2.json")
         if args.workload == "config2" and os.path.exists(pmc_file):
             allk = json.load(open(pmc_file))
             pmc = allk.get("dy::k_ibf_query_two") or allk.get("void dy::k_ibf_query<7>") or {}
