@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <thread>
 
@@ -108,6 +109,7 @@ struct dy_ctx
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
     size_t poolCap = 0;
+    PinnedBuf hostUp;                   // staging of dy_reads_upload
     PinnedBuf sparePinned[9];           // host arrays of fetched results, handed back by dy_result_free (hipHostMalloc costs milliseconds)
     DevBuf packCntSet, packCntOps, packOffSet, packOffOps, packReads, packSet, packOps;     // dy_result_fetch: dense copies made on the device
     DevBuf spare[12];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
@@ -786,20 +788,54 @@ int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, u
         std::unique_ptr<dy_reads> r(new dy_reads);
         r->ctx = ctx; r->n = n_reads; r->totalBases = offs[n_reads];
         u32 mx = 0, mn = 0xFFFFFFFFu;
+        r->lens->resize(n_reads);
+        u32 * lens = r->lens->data();
         for (u32 i = 0; i < n_reads; ++i)
         {
             if (offs[i + 1] < offs[i]) throw DyError(DY_EINVAL, "read offsets must be non-decreasing");
             u64 l = offs[i + 1] - offs[i];
             if (l > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");      // reference src/mapper.h:453-454
             mx = std::max<u32>(mx, (u32)l); mn = std::min<u32>(mn, (u32)l);
-            r->lens->push_back((u32)l);
+            lens[i] = (u32)l;
         }
         r->maxLen = mx; r->minLen = n_reads ? mn : 0;
-        r->seqs.reserve(r->totalBases + 64);
-        r->offs.reserve((size_t)(n_reads + 1) * 8);
-        if (r->totalBases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs, r->totalBases, hipMemcpyHostToDevice, ctx->stream));
+        // device buffers come from (and go back to) the context's pool: a batch per step would otherwise pay hipMalloc / hipFree
+        r->recycle = true;
+        takeBuffer(ctx, r->seqs, r->totalBases + 64);
+        takeBuffer(ctx, r->offs, (size_t)(n_reads + 1) * 8);
+        takeBuffer(ctx, r->seqsRc, r->totalBases + 64);
+        // The caller's memory is pageable: a few threads copy it chunk by chunk into a pinned staging buffer while the chunks already
+        // staged are on their way to the device (the runtime's own pageable path stages with one thread).
+        const size_t total = r->totalBases, CH = (size_t)8 << 20, nChunks = (total + CH - 1) / CH;
+        if (nChunks >= 4)
+        {
+            ctx->hostUp.reserve(total + 64);
+            u8 * stage = ctx->hostUp.as<u8>();
+            std::vector<std::atomic<int>> ready(nChunks);
+            for (auto & f : ready) f.store(0, std::memory_order_relaxed);
+            const unsigned T = (unsigned)std::min<size_t>(4, nChunks);
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T; ++t)
+                pool.emplace_back([&, t] {
+                    for (size_t c = t; c < nChunks; c += T)
+                    {
+                        const size_t at = c * CH, len = std::min(CH, total - at);
+                        memcpy(stage + at, seqs + at, len);
+                        ready[c].store(1, std::memory_order_release);
+                    }
+                });
+            hipError_t err = hipSuccess;
+            for (size_t c = 0; c < nChunks; ++c)
+            {
+                while (!ready[c].load(std::memory_order_acquire)) std::this_thread::yield();
+                const size_t at = c * CH, len = std::min(CH, total - at);
+                if (err == hipSuccess) err = hipMemcpyAsync(r->seqs.as<u8>() + at, stage + at, len, hipMemcpyHostToDevice, ctx->stream);
+            }
+            for (auto & th : pool) th.join();
+            HIP_CHECK(err);
+        }
+        else if (total) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs, total, hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK(hipMemcpyAsync(r->offs.p, offs, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        r->seqsRc.reserve(r->totalBases + 64);
         if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -824,7 +860,8 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         dy_ctx * ctx = f->ctx;
         HIP_CHECK(hipSetDevice(ctx->device));
         const u32 W = f->g.W;
-        reads->masks.reserve((size_t)reads->n * W * 8 + 8);
+        if (reads->recycle && !reads->masks.p) takeBuffer(ctx, reads->masks, (size_t)reads->n * W * 8 + 8);
+        else reads->masks.reserve((size_t)reads->n * W * 8 + 8);
         reads->maskW = W; reads->maskBins = f->g.nBins;
         if (reads->n)
         {
@@ -1025,7 +1062,8 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
 
         if (!p->use_filter)
         {
-            reads->masks.reserve((size_t)nReads * W * 8 + 8);
+            if (reads->recycle && !reads->masks.p) takeBuffer(ctx, reads->masks, (size_t)nReads * W * 8 + 8);
+            else reads->masks.reserve((size_t)nReads * W * 8 + 8);
             reads->maskW = W; reads->maskBins = nBins;
             if (nReads) hipLaunchKernelGGL(k_fill_masks, dim3((u32)(((u64)nReads * W + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins);
         }
