@@ -173,6 +173,43 @@ def test_ibf_low_thresholds_many_false_candidates(dy, ctx, ob, tmp_path, bins, b
     rd.close(); ibf.close(); oibf.close()
 
 
+def test_large_batch_upload_equals_small_batches(dy, ctx, ob, tmp_path):
+    """dy_reads_upload stages batches above 32 MB through pinned memory on several threads (8 MB chunks); the bin masks of one
+    40 MB batch must equal those of the same reads uploaded in small batches (plain copy path), and a sample must equal the oracle."""
+    rng = np.random.default_rng(2024)
+    bins, k = 8, 14
+    genomes = [rng.integers(0, 4, 30000, dtype=np.uint8) for _ in range(bins)]
+    goffs = np.arange(bins + 1, dtype=np.uint64) * np.uint64(30000)
+    path = str(tmp_path / "f.filter")
+    ob.build_filter(path, bins, 3, k, 1 << 22, np.concatenate(genomes), goffs)
+    n, L = 400000, 100
+    b = rng.integers(0, bins, n); s = rng.integers(0, 30000 - L, n)
+    big = np.stack(genomes)                                  # (bins, 30000)
+    codes2d = big[b[:, None], s[:, None] + np.arange(L)[None, :]].astype(np.uint8)
+    flip = rng.random(n) < 0.5
+    codes2d[flip] = 3 - codes2d[flip][:, ::-1]
+    codes2d[rng.random((n, L)) < 0.01] = 2
+    codes = np.ascontiguousarray(codes2d).reshape(-1)
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+    ibf = dy.Ibf.load(ctx, path)
+    thr = dy.threshold(np.float32(0.03), k, L)
+    rd = dy.Reads(ctx, codes, offs)
+    whole = ibf.query(rd, thr)
+    rd.close()
+    parts = []
+    for lo in range(0, n, 100000):
+        hi = lo + 100000
+        rp = dy.Reads(ctx, codes[lo * L:hi * L], offs[lo:hi + 1] - offs[lo])
+        parts.append(ibf.query(rp, thr))
+        rp.close()
+    assert np.array_equal(whole, np.concatenate(parts))
+    oibf = ob.OracleIbf(path)
+    sample = slice(390000, 400000)                           # the last chunks of the staged copy
+    assert np.array_equal(whole[sample], oibf.query(codes[390000 * L:], offs[390000:] - offs[390000], thr))
+    assert float((whole != 0).mean()) > 0.9
+    ibf.close(); oibf.close()
+
+
 def test_ibf_beyond_4gib_matches_oracle(dy, ctx, ob, tmp_path):
     """256 bins (W = 4) over a 5 GiB filter: word indices no longer fit 32 bits.  Filter built on the device, saved in
     the reference's file format, re-read by the oracle; masks must agree for reads sampled from the bins."""
