@@ -474,10 +474,14 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                 {
                     u32 * jobCount = ctx->counters.as<u32>() + 6;
                     hipLaunchKernelGGL(k_pe_rescue_jobs, dim3((nItems + 255) / 256), dim3(256), 0, st, V, ctx->peJobs.as<u32>(), jobCount);
-                    const u32 rescueBlocks = 512, rescueWaves = rescueBlocks * 4;
+                    const u32 rescueBlocks = 1024, rescueWaves = rescueBlocks * 4;
                     const size_t stride = (peRescueScratchBytes(reads->maxLen, maxWindow) + 63) & ~(size_t)63;
                     ctx->peScratch.reserve(stride * rescueWaves + 64);
-                    hipLaunchKernelGGL(k_pe_rescue, dim3(rescueBlocks), dim3(256), 0, st, fa, V, ctx->peJobs.as<u32>(), jobCount, ctx->peScratch.as<u8>(), stride, maxWindow);
+                    // the DP rows of a wavefront live in LDS when they fit (they do for ordinary libraries: 6 KB per wavefront at 100 bp / sigma 40)
+                    const size_t ldsWave = peRescueLdsBytes(reads->maxLen, maxWindow);
+                    const u32 ldsPerWave = ldsWave * 4 <= 60 * 1024 && !getenv("DY_PE_RESCUE_GLOBAL") ? (u32)ldsWave : 0u;
+                    hipLaunchKernelGGL(k_pe_rescue, dim3(rescueBlocks), dim3(256), (size_t)ldsPerWave * 4, st, fa, V, ctx->peJobs.as<u32>(), jobCount, ctx->peScratch.as<u8>(), stride,
+                                       maxWindow, ldsPerWave);
                 }
             }
             // room per read in the main mapper's match array: 3 per raw match + one per selected bin (a rescued mate)

@@ -540,9 +540,16 @@ __host__ __device__ inline size_t peRescueScratchBytes(u32 maxReadLen, u32 maxWi
     return (size_t)(maxReadLen + 1) * (maxWindow + 1) + 4 * (size_t)(maxWindow + 1) * sizeof(int) + maxReadLen + maxWindow + 64;
 }
 
-__global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, const u32 * __restrict__ jobs, const u32 * __restrict__ jobCount,
-                                                   u8 * __restrict__ scratch, size_t scratchStride, u32 maxWindow)
+// LDS bytes per wavefront for the rows + read + window of k_pe_rescue (the trace stays in the global slab)
+__host__ __device__ inline size_t peRescueLdsBytes(u32 maxReadLen, u32 maxWindow)
 {
+    return ((4 * (size_t)(maxWindow + 1) * sizeof(int) + maxReadLen + maxWindow + 15) & ~(size_t)15);
+}
+
+__global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, const u32 * __restrict__ jobs, const u32 * __restrict__ jobCount,
+                                                   u8 * __restrict__ scratch, size_t scratchStride, u32 maxWindow, u32 ldsPerWave)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 rescueLds[];
     const u32 lane = threadIdx.x & 63;
     const u32 gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 nWaves = (gridDim.x * blockDim.x) >> 6;
@@ -583,7 +590,9 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
         const int n = (int)(we - wb);
         const u8 * ctg = A.contigs + bd.contigOff + limits[anchor.contig] + wb;
         u8 * trace = my;
-        int * rowS0 = (int *)(my + (((size_t)(m + 1) * (n + 1) + 3) & ~(size_t)3));
+        // rows, read and window: in LDS when the launch reserved room for them (ldsPerWave > 0), else behind the trace in the global slab
+        int * rowS0 = ldsPerWave ? (int *)(rescueLds + (size_t)(threadIdx.x >> 6) * ldsPerWave)
+                                 : (int *)(my + (((size_t)(m + 1) * (n + 1) + 3) & ~(size_t)3));
         int * rowV0 = rowS0 + (n + 1), * rowS1 = rowV0 + (n + 1), * rowV1 = rowS1 + (n + 1);
         u8 * sRead = (u8 *)(rowV1 + (n + 1));
         u8 * sCtg = sRead + m;
