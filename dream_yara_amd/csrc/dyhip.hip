@@ -111,6 +111,7 @@ struct dy_ctx
     size_t poolCap = 0;
     PinnedBuf hostUp;                   // staging of dy_reads_upload
     PinnedBuf sparePinned[9];           // host arrays of fetched results, handed back by dy_result_free (hipHostMalloc costs milliseconds)
+    DevBuf sortKeys;                    // k_finalize_t<BlockGroup>: 128-bit sort keys of reads with more than SORT_CAP matches
     DevBuf packCntSet, packCntOps, packOffSet, packOffOps, packReads, packSet, packOps;     // dy_result_fetch: dense copies made on the device
     DevBuf spare[12];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
@@ -400,6 +401,8 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
         fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
         fa.debugFlags = getenv("DY_DEBUG_FINALIZE") ? (u32)atoi(getenv("DY_DEBUG_FINALIZE")) : 0;
+        fa.sortKeys = nullptr;
+        if (!paired && !getenv("DY_FINALIZE_NO_KEYS")) { ctx->sortKeys.reserve((size_t)nPool * 48 + 64); fa.sortKeys = ctx->sortKeys.as<u64>(); }
         ctx->complexList.reserve((size_t)nReads * 4 + 64);
         u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
         fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;

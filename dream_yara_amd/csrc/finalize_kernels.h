@@ -56,6 +56,7 @@ struct FinalizeArgs
     // reads that need the full aggregation (more than one raw match, or a gapped single match); the others were written by k_finalize_simple
     const u32 * complexList; const u32 * complexCount;
     u32 debugFlags;               // DY_DEBUG_FINALIZE (timing experiments only): 1 = skip the alignment DP, 2 = skip child passes
+    u64 * sortKeys;         // 6 words per raw match (per read: [6 * readStart, ...)), or nullptr
 };
 
 // libc++ std::default_random_engine (minstd_rand, seed 1) + uniform_int_distribution<size_t>(0, n-1), first draw
@@ -514,7 +515,7 @@ __host__ __device__ inline size_t dpScratchBytes(u32 maxReadLen, u32 maxErrors)
 // matches: repeats, low-complexity runs — one wavefront would sort them alone for seconds).  Same code, different primitives.
 struct WaveGroup
 {
-    enum : u32 { SIZE = 64, BLOCK = 256, PER_BLOCK = 4 };
+    enum : u32 { SIZE = 64, BLOCK = 256, PER_BLOCK = 4, SORT_CAP = 1 };
     __device__ static __forceinline__ u32 tid() { return threadIdx.x & 63; }
     __device__ static __forceinline__ u32 slot() { return threadIdx.x >> 6; }
     __device__ static __forceinline__ u32 groupId() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
@@ -538,7 +539,7 @@ struct WaveGroup
 
 struct BlockGroup
 {   // every thread of the block must make the same sequence of calls
-    enum : u32 { SIZE = 1024, BLOCK = 1024, PER_BLOCK = 1, NWAVES = 16 };
+    enum : u32 { SIZE = 1024, BLOCK = 1024, PER_BLOCK = 1, NWAVES = 16, SORT_CAP = 4096 };
     __device__ static __forceinline__ u32 tid() { return threadIdx.x; }
     __device__ static __forceinline__ u32 slot() { return 0; }
     __device__ static __forceinline__ u32 groupId() { return blockIdx.x; }
@@ -621,6 +622,123 @@ __device__ void groupSort(u32 * idx, u32 cnt, TLess less)
     }
 }
 
+// The three sort orders of the aggregation as 128-bit keys (hi, lo) with the element index in the low 23 bits of lo:
+// key(a, ia) < key(b, ib)  <=>  lessEnd / lessBegin / lessErrors (a, ia, b, ib).  MODE 0 = end, 1 = begin, 2 = errors.
+template <int MODE>
+__device__ __forceinline__ void sortKeyOf(const RawMatch & a, u32 i, u64 & hi, u64 & lo)
+{
+    const u64 loc = ((u64)a.bin << 17) | ((u64)a.contig << 1) | (u64)(a.strand & 1);      // 33 bits: (bin, contig, strand)
+    const u32 end = a.begin + a.len;
+    if (MODE == 0)      { hi = (loc << 31) | (end >> 1);     lo = ((u64)(end & 1) << 63)     | ((u64)a.errors << 55) | ((u64)a.begin << 23) | i; }
+    else if (MODE == 1) { hi = (loc << 31) | (a.begin >> 1); lo = ((u64)(a.begin & 1) << 63) | ((u64)a.errors << 55) | ((u64)end << 23)     | i; }
+    else                { hi = ((u64)a.errors << 56) | (loc << 23) | (a.begin >> 9); lo = ((u64)(a.begin & 511) << 55) | ((u64)end << 23) | i; }
+}
+
+// Sorts idx[0..cnt) (indices < nTotal into R) by the order MODE.  A block sorts keys instead of indices: up to SORT_CAP elements
+// entirely in LDS (sKeys holds 2 * SORT_CAP words); more than that with the keys in the global area gKeys (2 * cnt words): the steps
+// of the network whose partners lie inside a SORT_CAP-aligned tile run tile by tile in LDS, only the wider ones go through global
+// memory (coalesced 16-byte elements instead of index -> record gathers).  The network is waveSort's (valid for any cnt: ascending
+// compare-exchanges, mirror partner on the first step of a merge).  Everything else takes groupSort with the comparator of the same
+// order; all give the one permutation the strict total order defines.
+template <typename G, int MODE>
+__device__ void groupSortKeyed(u32 * idx, u32 cnt, const RawMatch * R, u32 nTotal, u64 * sKeys, u64 * gKeys)
+{
+    if constexpr (G::SIZE != 64)
+    {
+        const u32 CAP = G::SORT_CAP;
+        u64 * sHi = sKeys, * sLo = sKeys + CAP;
+        auto exchangeLds = [&](u32 li, u32 ll) {
+            const u64 ah = sHi[li], al = sLo[li], bh = sHi[ll], bl = sLo[ll];
+            if (bh < ah || (bh == ah && bl < al)) { sHi[li] = bh; sLo[li] = bl; sHi[ll] = ah; sLo[ll] = al; }
+        };
+        if (cnt > 1 && cnt <= CAP && nTotal <= (1u << 23))
+        {
+            for (u32 i = G::tid(); i < cnt; i += G::SIZE) { const u32 e = idx[i]; u64 hi, lo; sortKeyOf<MODE>(R[e], e, hi, lo); sHi[i] = hi; sLo[i] = lo; }
+            __syncthreads();
+            for (u32 k = 2; (k >> 1) < cnt; k <<= 1)
+                for (u32 j = k >> 1, first = 1; j > 0; j >>= 1, first = 0)
+                {
+                    for (u32 i = G::tid(); i < cnt; i += G::SIZE)
+                    {
+                        const u32 l = first ? (i ^ (k - 1)) : (i ^ j);
+                        if (l > i && l < cnt) exchangeLds(i, l);
+                    }
+                    __syncthreads();
+                }
+            for (u32 i = G::tid(); i < cnt; i += G::SIZE) idx[i] = (u32)(sLo[i] & 0x7FFFFFu);
+            __syncthreads();
+            return;
+        }
+        if (cnt > CAP && gKeys && nTotal <= (1u << 23))
+        {
+            u64 * gHi = gKeys, * gLo = gKeys + cnt;
+            for (u32 i = G::tid(); i < cnt; i += G::SIZE) { const u32 e = idx[i]; u64 hi, lo; sortKeyOf<MODE>(R[e], e, hi, lo); gHi[i] = hi; gLo[i] = lo; }
+            __syncthreads();
+            // steps kFrom.. of the network restricted to partners inside a tile: kFrom = 2 sorts every tile (merges up to CAP);
+            // kFrom = 0 runs only the xor steps j = CAP/2 .. 1 that finish a merge wider than a tile
+            auto tiles = [&](bool wholeSort) {
+                for (u32 base = 0; base < cnt; base += CAP)
+                {
+                    const u32 len = cnt - base < CAP ? cnt - base : CAP;
+                    for (u32 li = G::tid(); li < len; li += G::SIZE) { sHi[li] = gHi[base + li]; sLo[li] = gLo[base + li]; }
+                    __syncthreads();
+                    if (wholeSort)
+                    {
+                        for (u32 k = 2; k <= CAP; k <<= 1)
+                            for (u32 j = k >> 1, first = 1; j > 0; j >>= 1, first = 0)
+                            {
+                                for (u32 li = G::tid(); li < len; li += G::SIZE)
+                                {
+                                    const u32 ll = first ? (li ^ (k - 1)) : (li ^ j);
+                                    if (ll > li && ll < len) exchangeLds(li, ll);
+                                }
+                                __syncthreads();
+                            }
+                    }
+                    else
+                    {
+                        for (u32 j = CAP >> 1; j > 0; j >>= 1)
+                        {
+                            for (u32 li = G::tid(); li < len; li += G::SIZE)
+                            {
+                                const u32 ll = li ^ j;
+                                if (ll > li && ll < len) exchangeLds(li, ll);
+                            }
+                            __syncthreads();
+                        }
+                    }
+                    for (u32 li = G::tid(); li < len; li += G::SIZE) { gHi[base + li] = sHi[li]; gLo[base + li] = sLo[li]; }
+                    __syncthreads();
+                }
+            };
+            tiles(true);
+            for (u32 k = 2 * CAP; (k >> 1) < cnt; k <<= 1)
+            {
+                for (u32 j = k >> 1, first = 1; j >= CAP; j >>= 1, first = 0)
+                {
+                    for (u32 i = G::tid(); i < cnt; i += G::SIZE)
+                    {
+                        const u32 l = first ? (i ^ (k - 1)) : (i ^ j);
+                        if (l > i && l < cnt)
+                        {
+                            const u64 ah = gHi[i], al = gLo[i], bh = gHi[l], bl = gLo[l];
+                            if (bh < ah || (bh == ah && bl < al)) { gHi[i] = bh; gLo[i] = bl; gHi[l] = ah; gLo[l] = al; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                tiles(false);
+            }
+            for (u32 i = G::tid(); i < cnt; i += G::SIZE) idx[i] = (u32)(gLo[i] & 0x7FFFFFu);
+            __syncthreads();
+            return;
+        }
+    }
+    if (MODE == 0)      groupSort<G>(idx, cnt, [&](u32 a, u32 b) { return lessEnd(R[a], a, R[b], b); });
+    else if (MODE == 1) groupSort<G>(idx, cnt, [&](u32 a, u32 b) { return lessBegin(R[a], a, R[b], b); });
+    else                groupSort<G>(idx, cnt, [&](u32 a, u32 b) { return lessErrors(R[a], a, R[b], b); });
+}
+
 // Reads of the complex list with minN <= #matches <= maxN, one group G per read.
 template <typename G>
 __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 minN, u32 maxN, u32 dpSlabBase)
@@ -636,6 +754,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
     __shared__ RawMatch sE[G::PER_BLOCK][SMALL_N];
     __shared__ RawMatch sM[G::PER_BLOCK][3 * SMALL_N];
     __shared__ u32 sIdx[G::PER_BLOCK][8 * SMALL_N];
+    __shared__ u64 sKeys[2 * G::SORT_CAP];        // key sort of a block (groupSortKeyed); a token word for the wavefront variant
 
     const u32 nList = *A.complexCount;
     for (u32 li = gwave; li < nList; li += nWaves)
@@ -656,11 +775,12 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
         RawMatch * M = small ? sM[wv] : A.marr + (size_t)3 * s0;                // the main mapper's matchesByCoord of this read
         u32 * idxM = small ? sIdx[wv] + 2 * SMALL_N : A.maux + (size_t)6 * s0;  // 3n
         u32 * idxF = idxM + (size_t)3 * n;                                      // 3n
+        u64 * gKeys = A.sortKeys ? A.sortKeys + (size_t)6 * s0 : nullptr;       // 2 x 3n words: keys of the sort in progress (block variant, > SORT_CAP elements)
 
         // ---- child mappers: one (read, bin) segment at a time, bins in ascending order
         for (u32 i = lane; i < n; i += G::SIZE) idxA[i] = i;
         G::fence();
-        groupSort<G>(idxA, n, [&](u32 a, u32 b) { return lessEnd(E[a], a, E[b], b); });
+        groupSortKeyed<G, 0>(idxA, n, E, n, sKeys, gKeys);
         u32 nM = 0;
         u32 winErr = 256, winRank = 0;                 // copyCigars: last processed bin among those with the minimal errors
         u32 p0 = 0;
@@ -693,7 +813,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
             }
             G::fence();
             // pass 2 (ContigBegin) over the n1 survivors
-            groupSort<G>(idxB, n1, [&](u32 a, u32 b) { return lessBegin(E[a], a, E[b], b); });
+            groupSortKeyed<G, 1>(idxB, n1, E, n, sKeys, gKeys);
             u32 n2 = 0, myMin = 255;
             for (u32 base = 0; base < n1; base += G::SIZE)
             {
@@ -794,7 +914,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
         // ---- main mapper: aggregateMatches + rankMatches2 over the union
         for (u32 i = lane; i < nM; i += G::SIZE) idxM[i] = i;
         G::fence();
-        groupSort<G>(idxM, nM, [&](u32 a, u32 b) { return lessEnd(M[a], a, M[b], b); });
+        groupSortKeyed<G, 0>(idxM, nM, M, nM, sKeys, gKeys);
         u32 m1 = 0;
         for (u32 base = 0; base < nM; base += G::SIZE)
         {
@@ -810,7 +930,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
             if (first) idxF[slot] = idxM[p];
         }
         G::fence();
-        groupSort<G>(idxF, m1, [&](u32 a, u32 b) { return lessBegin(M[a], a, M[b], b); });
+        groupSortKeyed<G, 1>(idxF, m1, M, nM, sKeys, gKeys);
         u32 m2 = 0;
         for (u32 base = 0; base < m1; base += G::SIZE)
         {
@@ -826,7 +946,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
             if (first) idxM[slot] = idxF[q];
         }
         G::fence();
-        groupSort<G>(idxM, m2, [&](u32 a, u32 b) { return lessErrors(M[a], a, M[b], b); });
+        groupSortKeyed<G, 2>(idxM, m2, M, nM, sKeys, gKeys);
         const u32 minE = M[idxM[0]].errors;
         const u32 strata = readStrataOf(readLen, A.strataRate);
         u32 cOpt = 0, cSet = 0;

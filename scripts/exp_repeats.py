@@ -15,6 +15,8 @@ for b, g in enumerate(genomes):
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 PAIRED = len(sys.argv) > 2 and sys.argv[2] == "paired"      # first half / second half of the batch as mates (unrelated: exercises the path only)
 codes, offs = _sample_reads(rng, genomes, fam, N, 100, 3)
+if "nopolya" in sys.argv:      # drop the two poly-A reads that _sample_reads appends (about 10^6 matches each)
+    offs = offs[:-2]; codes = codes[:int(offs[-1])]; N -= 2
 ctx = dy.Context(0); idx = dy.Index(ctx, idx_dir, n_bins); rd = dy.Reads(ctx, codes, offs)
 params = dy.default_params(error_rate=np.float32(0.03)); params.use_filter = 0
 if PAIRED: params.paired = 1
@@ -22,6 +24,11 @@ for it in range(3):
     t0 = time.perf_counter()
     res = dy.map_reads(ctx, idx, rd, params, asynchronous=True); ctx.sync()
     dt = time.perf_counter() - t0
-    st = ctx.stats(); res.close()
+    st = ctx.stats()
+    if it == 2:
+        import hashlib
+        res.fetch()
+        digest = hashlib.sha1(res.reads().tobytes() + res.matches().tobytes() + res.cigars().tobytes()).hexdigest()[:16]
+    res.close()
 print("reads", N + 2, "items", st["items"], "hard", st["hard_items"], "raw matches", st["raw_matches"], "ms total %.1f" % (1e3 * dt),
-      {k: round(st[k], 2) for k in ("ms_items", "ms_search", "ms_extend", "ms_finalize")}, "pool retries", st["pool_retries"], "paired" if PAIRED else "single-end")
+      {k: round(st[k], 2) for k in ("ms_items", "ms_search", "ms_extend", "ms_finalize")}, "pool retries", st["pool_retries"], "paired" if PAIRED else "single-end", "result sha1", digest)
