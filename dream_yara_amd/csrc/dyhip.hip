@@ -331,7 +331,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
         ctx->hardList.reserve((size_t)nItems * 4 + 64);
         if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
-        u32 hostCounters[4] = {0, 0, 0, 0};     // [0] pool count, [1] overflow flag, [2] hard items
+        u32 hostCounters[16] = {0};             // [0] pool count, [1] overflow flag, [2] items of the wavefront-per-item list, [12] those of them that are busy but not re-seeded
         const int nw = (int)((reads->maxLen + 63) / 64);
         for (;;)
         {
@@ -348,7 +348,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
                 else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink);
                 HIP_CHECK(hipGetLastError());
             }
-            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, 16, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, 64, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
             if (!hostCounters[1]) break;
             if (hostCounters[0] >= 0xFFFFFFF0u) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
@@ -357,7 +357,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         }
         HIP_CHECK(hipEventRecord(ctx->ev[5], st));
         const u32 nPool = hostCounters[0];
-        ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2];
+        ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12];     // re-seeded items, as the reference counts them
 
         nItemsOut = nItems; nPoolOut = nPool;
 }

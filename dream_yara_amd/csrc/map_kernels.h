@@ -600,13 +600,19 @@ __global__ __launch_bounds__(1024) void k_item_order_scatter(const u32 * __restr
 }
 
 // classifyReads for one item (reference src/mapper_classifier.h:111-155): 0 = easy, 1 / 2 = re-seed with that many seed errors
-__device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S0, const MapParams & prm)
+__device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S0, const MapParams & prm, u64 & total)
 {
-    u64 total = 0;
+    total = 0;
     for (u32 s = 0; s < 2 * S0; ++s) total += hitCount(h0[s]);
     if (total > prm.hitsThreshold) return (total < 2ull * 200 * prm.hitsThreshold) ? 1 : 2;
     return 0;
 }
+__device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S0, const MapParams & prm) { u64 total; return classifyItem(h0, S0, prm, total); }
+// An item that is not re-seeded but has this many exact seed hits still goes to the wavefront-per-item kernel (same result: with
+// seedErrors = 0 it runs the exact round only): one lane would extend them one after the other while its 63 neighbours wait.
+#ifndef DY_BUSY_ITEM_HITS
+#define DY_BUSY_ITEM_HITS 64
+#endif
 
 // Easy items (seedErrors == 0): rankSeeds + extendHits<0>(bucket 0) for the whole wavefront.
 // Every lane walks its own (rank, strand, SA row) sequence — seeds by ascending hit count, ties keep ascending seed
@@ -632,7 +638,9 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
         binContigs = ix.contigs + ix.bins[bin].contigOff; binLimits = ix.limits + ix.bins[bin].limOff;
         h0 = hits0 + (size_t)item * 2 * S0;
         cnt0 = seedCountOf(readErrors, 0);
-        seedErrors = classifyItem(h0, S0, prm);
+        u64 totalHits;
+        seedErrors = classifyItem(h0, S0, prm, totalHits);
+        if (seedErrors == 0 && totalHits > DY_BUSY_ITEM_HITS) { seedErrors = 3; atomicAdd(hardCount + 10, 1u); }   // not re-seeded, just busy (counted apart: counters[12]); any non-zero value keeps it out of this kernel
         if (seedErrors) hardList[atomicAdd(hardCount, 1u)] = item;          // left to k_extend_hard
     }
     bool active = valid && seedErrors == 0 && len >= cnt0;
