@@ -374,7 +374,7 @@ struct ItemState
 {
     u32 minErrors;     // 255 = none yet (ReadsContext::minErrors, reference src/bits_context.h:86)
     bool mapped;
-    // the first two matches of an item are kept in registers and appended with ONE pool reservation per wavefront at
+    // the first two matches of an item are kept in registers and appended with ONE pool reservation per block at
     // the end of the kernel (a single shared counter saturates at ~10^8 atomics/s); further matches go straight to the pool
     RawMatch buf0, buf1;
     u32 nbuf;
@@ -695,29 +695,6 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
 #define DY_K3_WAVES 4      // waves per SIMD the easy-path kernel is compiled for at NW <= 2 (measured: 4 -> 1.10 ms, 5 -> 1.11 ms, 6 -> 1.20 ms: spills eat the gain)
 #endif
 
-// one pool reservation per wavefront for the matches buffered in the lanes' ItemStates
-__device__ __forceinline__ void flushWaveMatches(const ItemState & st, u32 read, const MatchSink & sink, u32 lane)
-{
-    const u32 cnt = st.nbuf;
-    u32 incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
-    const u32 total = __shfl(incl, 63, 64);
-    if (!total) return;
-    u32 base = 0;
-    if (lane == 63) base = atomicAdd(sink.poolCount, total);
-    base = __shfl(base, 63, 64);
-    const u32 first = base + incl - cnt;
-    if (cnt >= 1)
-    {
-        if (first < sink.poolCap) { sink.pool[first] = st.buf0; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
-    }
-    if (cnt >= 2)
-    {
-        if (first + 1 < sink.poolCap) { sink.pool[first + 1] = st.buf1; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
-    }
-}
-
 // Hard item: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2), Hamming backtracking in the FM index.
 // ONE WAVEFRONT PER ITEM: a re-seeded read has hundreds to hundreds of thousands of seed occurrences, so the trie walk (cheap) is
 // done by all lanes in step and the SA rows of every leaf are dealt to the 64 lanes, each extending its own occurrence.  A rank is
@@ -813,7 +790,8 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
     }
 }
 
-// same, one pool reservation per BLOCK (same-address atomics are served one at a time; every thread of the block must call this)
+// one pool reservation per BLOCK for the matches buffered in the threads' ItemStates (same-address atomics are served one at a time;
+// every thread of the block must call this)
 __device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read, const MatchSink & sink, u32 lane)
 {
     __shared__ u32 waveOff[16];
