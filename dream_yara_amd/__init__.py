@@ -70,6 +70,7 @@ SYMBOLS = [
     ("dy_ibf_add", C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
     ("dy_ibf_save", C.c_int, [_P, C.c_char_p]),
     ("dy_ibf_get_info", C.c_int, [_P, C.POINTER(IbfInfo)]),
+    ("dy_ibf_read_words", C.c_int, [_P, C.c_uint64, C.c_uint64, _P]),
     ("dy_ibf_free", None, [_P]),
     ("dy_ibf_threshold", C.c_uint16, [C.c_float, C.c_uint32, C.c_uint16]),
     ("dy_reads_upload", C.c_int, [_P, _P, _P, C.c_uint32, C.POINTER(_P)]),
@@ -200,6 +201,13 @@ class Ibf:
         i = IbfInfo()
         _check(self.lib.dy_ibf_get_info(self.h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in IbfInfo._fields_}
+
+    def words(self):
+        """The filter's 64-bit words as dy_ibf_save() writes them (trailer included): (uint64 array, n_bits)."""
+        n_bits = self.info()["n_bits"]
+        out = np.empty(n_bits // 64, dtype=np.uint64)
+        _check(self.lib.dy_ibf_read_words(self.h, 0, out.size, out.ctypes.data))
+        return out, n_bits
 
     def query(self, reads, threshold, want_masks=True):
         """whichBins(fwd) | whichBins(revcomp) per read -> (n_reads, W) uint64 (or None)."""

@@ -61,6 +61,14 @@ struct DevBuf
         HIP_CHECK(hipMalloc(&p, want));
         cap = want;
     }
+    // no growth slack: objects of tens of GiB that never grow (the filter)
+    void reserveExact(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIP_CHECK(hipMalloc(&p, bytes + 256));
+        cap = bytes + 256;
+    }
     template <typename T> T * as() const { return (T *)p; }
     void moveTo(DevBuf & o) { if (o.p) (void)hipFree(o.p); o.p = p; o.cap = cap; p = nullptr; cap = 0; }
 };
@@ -637,7 +645,7 @@ int dy_ibf_create(dy_ctx * ctx, uint32_t n_bins, uint32_t n_hashes, uint32_t kme
         f->ctx = ctx;
         initGeom(f->g, n_bins, n_hashes, kmer_size, n_bits);
         f->nWords = (size_t)(n_bits / 64);
-        f->words.reserve(f->nWords * 8 + 8);
+        f->words.reserveExact(f->nWords * 8 + 8);
         HIP_CHECK(hipMemsetAsync(f->words.p, 0, f->nWords * 8 + 8, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *out = f.release();
@@ -656,7 +664,7 @@ int dy_ibf_load(dy_ctx * ctx, const char * path, dy_ibf ** out)
         f->ctx = ctx;
         initGeom(f->g, bins, hashes, k, ff.nBits);
         f->nWords = ff.nWords;
-        f->words.reserve(f->nWords * 8 + 8);
+        f->words.reserveExact(f->nWords * 8 + 8);
         HIP_CHECK(hipMemcpy(f->words.p, ff.words, f->nWords * 8, hipMemcpyHostToDevice));
         *out = f.release();
     });
@@ -686,7 +694,7 @@ int dy_kdx_create(dy_ctx * ctx, uint32_t n_bins, uint32_t kmer_size, dy_ibf ** o
         f->ctx = ctx;
         initGeom(f->g, n_bins, 1, kmer_size, bits);
         f->nWords = (size_t)(bits / 64);
-        f->words.reserve((f->nWords + W + 8) * 8);
+        f->words.reserveExact((f->nWords + W + 8) * 8);
         HIP_CHECK(hipMemsetAsync(f->words.p, 0, (f->nWords + W + 8) * 8, ctx->stream));
         makeDirect(ctx, f.get());
         *out = f.release();
@@ -705,7 +713,7 @@ int dy_kdx_load(dy_ctx * ctx, const char * path, dy_ibf ** out)
         f->ctx = ctx;
         initGeom(f->g, bins, 1, k, ff.nBits);
         f->nWords = ff.nWords;
-        f->words.reserve((f->nWords + f->g.W + 8) * 8);
+        f->words.reserveExact((f->nWords + f->g.W + 8) * 8);
         HIP_CHECK(hipMemcpy(f->words.p, ff.words, f->nWords * 8, hipMemcpyHostToDevice));
         makeDirect(ctx, f.get());
         *out = f.release();
@@ -765,6 +773,25 @@ int dy_ibf_save(dy_ibf * f, const char * path)
         bool ok = fwrite(&f->g.nBits, 8, 1, fp) == 1 && fwrite(host.data(), 8, host.size(), fp) == host.size();
         fclose(fp);
         if (!ok) throw IoError(std::string("short write to ") + path);
+    });
+}
+
+int dy_ibf_read_words(dy_ibf * f, uint64_t first_word, uint64_t n_words, uint64_t * words_host)
+{
+    return guarded([&] {
+        if (!f || (!words_host && n_words)) throw DyError(DY_EINVAL, "dy_ibf_read_words: NULL argument");
+        if (first_word > f->nWords || n_words > f->nWords - first_word) throw DyError(DY_EINVAL, "dy_ibf_read_words: range exceeds the filter");
+        if (!n_words) return;
+        HIP_CHECK(hipSetDevice(f->ctx->device));
+        HIP_CHECK(hipStreamSynchronize(f->ctx->stream));
+        // large copies go chunk by chunk so that the runtime's pageable staging stays small
+        const u64 CH = (u64)1 << 27;
+        for (u64 at = 0; at < n_words; at += CH)
+            HIP_CHECK(hipMemcpy(words_host + at, f->words.as<u64>() + first_word + at, (size_t)std::min(CH, n_words - at) * 8, hipMemcpyDeviceToHost));
+        const u64 ms = (f->g.nBits - 256) / 64;                 // _setMetadata, reference src/d_bloom_filter.h:267-277
+        const u64 meta[4] = {f->g.nBins, f->g.direct ? 0u : f->g.nHashes, f->g.kmerSize, 0};
+        for (u64 i = 0; i < 4; ++i)
+            if (ms + i >= first_word && ms + i < first_word + n_words) words_host[ms + i - first_word] = meta[i];
     });
 }
 

@@ -70,6 +70,10 @@ int  dy_ibf_add(dy_ibf *f, const uint8_t *seq, uint64_t len, uint32_t bin);
 /* save() — reference src/d_bloom_filter.h:150-154 (sdsl bit_vector file with the metadata trailer). */
 int  dy_ibf_save(dy_ibf *f, const char *path);
 int  dy_ibf_get_info(const dy_ibf *f, dy_ibf_info *info);
+/* sdsl::bit_vector::data() / get_int — reference src/d_bloom_filter.h:190-193,262-264: copies the filter's 64-bit words
+ * [first_word, first_word + n_words) to host memory, exactly as dy_ibf_save() would write them after the 8-byte bit count
+ * (metadata trailer included).  n_bits/64 words in total. */
+int  dy_ibf_read_words(dy_ibf *f, uint64_t first_word, uint64_t n_words, uint64_t *words_host);
 void dy_ibf_free(dy_ibf *f);
 /* DisOptions::getThreshold — reference src/d_mapper.h:83-92.  error_rate is the float the CLI stores (e/100.0). */
 uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len);

@@ -356,18 +356,28 @@ public:
             for (size_t i = 0; i < n; ++i) lengthSum += 2 * reads.fwd[i].size();
             u16 avg = (u16)(lengthSum / (n * 2));
             u16 thr = getThreshold(opt, filter->kmerSize, avg);
-            for (size_t p = 0; p < P; ++p)
-            {
-                std::vector<bool> sel(numBins, thr == 0);
-                if (thr)
-                    for (size_t r : {p, p + P})
+            // the votes of different pairs are independent: computed on opt.threads threads, appended in pair order
+            std::vector<std::vector<bool> > sels(P);
+            const unsigned T = std::max(1u, opt.threads);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; ++t)
+                th.emplace_back([&, t] {
+                    for (size_t p = t; p < P; p += T)
                     {
-                        if (reads.fwd[r].size() < filter->kmerSize) continue;
-                        ibfWhichBins(*filter, sel, reads.fwd[r].data(), reads.fwd[r].size(), thr);
-                        ibfWhichBins(*filter, sel, reads.rev[r].data(), reads.rev[r].size(), thr);
+                        std::vector<bool> & sel = sels[p];
+                        sel.assign(numBins, thr == 0);
+                        if (thr)
+                            for (size_t r : {p, p + P})
+                            {
+                                if (reads.fwd[r].size() < filter->kmerSize) continue;
+                                ibfWhichBins(*filter, sel, reads.fwd[r].data(), reads.fwd[r].size(), thr);
+                                ibfWhichBins(*filter, sel, reads.rev[r].data(), reads.rev[r].size(), thr);
+                            }
                     }
-                for (u32 b = 0; b < numBins; ++b) if (sel[b]) pairMap[b].push_back((u32)p);
-            }
+                });
+            for (auto & x : th) x.join();
+            for (size_t p = 0; p < P; ++p)
+                for (u32 b = 0; b < numBins; ++b) if (sels[p][b]) pairMap[b].push_back((u32)p);
         }
         if (stats) { stats->readsPerBin.assign(numBins, 0); for (u32 b = 0; b < numBins; ++b) { stats->readsPerBin[b] = 2 * pairMap[b].size(); stats->filteredReads += 2 * pairMap[b].size(); } }
         std::vector<u32> order(numBins);
@@ -390,15 +400,20 @@ public:
             struct Child { std::vector<Match> all; size_t nu = 0; std::vector<size_t> byErr; size_t nOpt = 0, nSet = 0; size_t primary = (size_t)-1;
                            bool mapped = false, paired = false; double prob = 0; bool rescued = false; Match mate; std::vector<CigarOp> cigar; };
             std::vector<Child> ch(2 * Pc);
-            ReadBinMapper mapper(bin, opt);
+            // the child mapper's per-read stage has no cross-read state: reads go to opt.threads threads (pairing below stays sequential)
             BinMapStats bst;
-            for (size_t r = 0; r < 2 * Pc; ++r)
+            const unsigned Tc = (unsigned)std::min<size_t>(std::max(1u, opt.threads), std::max<size_t>(1, 2 * Pc / 64));
+            std::vector<BinMapStats> tst(Tc);
+            std::vector<std::thread> cth;
+            for (unsigned t = 0; t < Tc; ++t) cth.emplace_back([&, t] {
+            ReadBinMapper mapper(bin, opt);
+            for (size_t r = t; r < 2 * Pc; r += Tc)
             {
                 size_t orig = origOf(r);
                 unsigned L = (unsigned)reads.fwd[orig].size();
                 const u8 * seqs[2] = {reads.fwd[orig].data(), reads.rev[orig].data()};
                 Child & c = ch[r];
-                mapper.map(seqs, L, (u32)orig, c.all, stats ? &bst : nullptr);
+                mapper.map(seqs, L, (u32)orig, c.all, stats ? &tst[t] : nullptr);
                 if (c.all.empty()) continue;
                 c.nu = removeDuplicates(c.all);
                 c.byErr.resize(c.nu); std::iota(c.byErr.begin(), c.byErr.end(), (size_t)0);
@@ -409,6 +424,9 @@ public:
                 c.primary = c.byErr[(size_t)libcxxFirstUniform(c.nOpt)];
                 c.mapped = true;
             }
+            });
+            for (auto & x : cth) x.join();
+            for (auto & x : tst) { bst.seeds += x.seeds; bst.hits += x.hits; bst.located += x.located; bst.extended += x.extended; bst.matches += x.matches; }
             if (stats) { stats->bin.seeds += bst.seeds; stats->bin.hits += bst.hits; stats->bin.located += bst.located; stats->bin.extended += bst.extended; stats->bin.matches += bst.matches; }
             // ---- library mean / deviation from unique proper pairs (src/mapper.h:929-985)
             unsigned libraryLength = 0, libraryDev = 0;

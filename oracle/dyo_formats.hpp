@@ -273,6 +273,8 @@ struct IBF
     bool direct = false;      // k-mer direct-addressing filter (reference src/d_kdx_filter.h): position = the k-mer's own hash
     std::vector<u64> preCalc;
     std::vector<u64> words;   // ceil(bits/64)
+    const u64 * view = nullptr; // read-only words owned by the caller (tests hand over a filter copied back from the device)
+    const u64 * data() const { return view ? view : words.data(); }
 
     static const u64 SEED = 0x90b45d39fb6da1faull;   // src/d_bloom_filter.h:330
     static const unsigned SHIFT = 27;                // :329
@@ -294,8 +296,9 @@ struct IBF
     inline u64 getInt(u64 idx) const
     {
         u64 w = idx >> 6; unsigned o = idx & 63;
-        if (!o) return words[w];
-        return (words[w] >> o) | (words[w + 1] << (64 - o));
+        const u64 * d = data();
+        if (!o) return d[w];
+        return (d[w] >> o) | (d[w + 1] << (64 - o));
     }
     // reference src/d_build_filter.cpp:305-312: 4^k positions of `bins` bits (+ trailer); defined for bins % 64 == 0
     void createDirect(u32 bins, u32 k)
@@ -324,6 +327,14 @@ struct IBF
         fwrite(&noOfBits, 8, 1, f);
         fwrite(words.data(), 8, words.size(), f);
         fclose(f);
+    }
+    // a filter whose words already sit in memory (same layout as the file after its 8-byte bit count, trailer included)
+    void attach(const u64 * w, u64 bits, bool asDirect = false)
+    {
+        direct = asDirect; view = w; noOfBits = bits;
+        u64 ms = noOfBits - 256;
+        noOfBins = (u32)getInt(ms); noOfHashFunc = (u32)getInt(ms + 64); kmerSize = (u32)getInt(ms + 128);
+        init();
     }
     void load(const std::string & path, bool asDirect = false)
     {

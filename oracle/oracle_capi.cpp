@@ -33,6 +33,11 @@ void * dyo_ibf_load(const char * path)
 {
     try { IBF * f = new IBF; f->load(path); return f; } catch (std::exception const & e) { g_err = e.what(); return nullptr; }
 }
+// read-only view of filter words already in memory (tests: a filter copied back from the device); the caller keeps them alive
+void * dyo_ibf_attach(const u64 * words, u64 nBits, int direct)
+{
+    try { IBF * f = new IBF; f->attach(words, nBits, direct != 0); return f; } catch (std::exception const & e) { g_err = e.what(); return nullptr; }
+}
 void * dyo_kdx_load(const char * path)
 {
     try { IBF * f = new IBF; f->load(path, true); return f; } catch (std::exception const & e) { g_err = e.what(); return nullptr; }
@@ -56,29 +61,41 @@ void dyo_ibf_free(void * f) { delete (IBF *)f; }
 void dyo_ibf_info(void * f, u64 * out) { IBF * i = (IBF *)f; out[0] = i->noOfBits; out[1] = i->noOfBins; out[2] = i->noOfHashFunc; out[3] = i->kmerSize; out[4] = i->binIntWidth; out[5] = i->noOfHashPos; }
 
 // whichBins(fwd) | whichBins(revcomp) per read, W words each
-int dyo_ibf_query(void * fv, const u8 * seqs, const u64 * offs, u32 n, u16 threshold, u64 * masks)
+static void ibfQueryRange(IBF & f, const u8 * seqs, const u64 * offs, u32 lo, u32 hi, u32 step, u16 threshold, u64 * masks)
+{
+    for (u32 i = lo; i < hi; i += step)
+    {
+        size_t len = (size_t)(offs[i + 1] - offs[i]);
+        std::vector<u8> rc(len);
+        for (size_t k = 0; k < len; ++k) { u8 c = seqs[offs[i] + len - 1 - k]; rc[k] = c < 4 ? (u8)(3 - c) : (u8)4; }
+        std::vector<bool> sel(f.noOfBins, false);
+        if (len >= f.kmerSize)
+        {
+            ibfWhichBins(f, sel, seqs + offs[i], len, threshold);
+            ibfWhichBins(f, sel, rc.data(), len, threshold);
+        }
+        else if (threshold == 0) sel.assign(f.noOfBins, true);
+        for (u32 w = 0; w < f.binIntWidth; ++w) masks[(size_t)i * f.binIntWidth + w] = 0;
+        for (u32 b = 0; b < f.noOfBins; ++b) if (sel[b]) masks[(size_t)i * f.binIntWidth + b / 64] |= 1ull << (b % 64);
+    }
+}
+int dyo_ibf_query_mt(void * fv, const u8 * seqs, const u64 * offs, u32 n, u16 threshold, u64 * masks, unsigned threads)
 {
     try
     {
         IBF & f = *(IBF *)fv;
-        for (u32 i = 0; i < n; ++i)
-        {
-            size_t len = (size_t)(offs[i + 1] - offs[i]);
-            std::vector<u8> rc(len);
-            for (size_t k = 0; k < len; ++k) { u8 c = seqs[offs[i] + len - 1 - k]; rc[k] = c < 4 ? (u8)(3 - c) : (u8)4; }
-            std::vector<bool> sel(f.noOfBins, false);
-            if (len >= f.kmerSize)
-            {
-                ibfWhichBins(f, sel, seqs + offs[i], len, threshold);
-                ibfWhichBins(f, sel, rc.data(), len, threshold);
-            }
-            else if (threshold == 0) sel.assign(f.noOfBins, true);
-            for (u32 w = 0; w < f.binIntWidth; ++w) masks[(size_t)i * f.binIntWidth + w] = 0;
-            for (u32 b = 0; b < f.noOfBins; ++b) if (sel[b]) masks[(size_t)i * f.binIntWidth + b / 64] |= 1ull << (b % 64);
-        }
+        const unsigned T = std::max(1u, threads);
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; ++t) th.emplace_back([&, t] { ibfQueryRange(f, seqs, offs, t, n, T, threshold, masks); });
+        ibfQueryRange(f, seqs, offs, 0, n, T, threshold, masks);
+        for (auto & x : th) x.join();
         return 0;
     }
     catch (std::exception const & e) { g_err = e.what(); return -1; }
+}
+int dyo_ibf_query(void * fv, const u8 * seqs, const u64 * offs, u32 n, u16 threshold, u64 * masks)
+{
+    return dyo_ibf_query_mt(fv, seqs, offs, n, threshold, masks, 1);
 }
 
 // build a filter file: one bin per sequence (codes), for tests
@@ -174,6 +191,11 @@ void * dyo_map_batch_paired(void * idxv, void * ibfv, const u8 * seqs, const u64
                             unsigned hitsThreshold, unsigned libraryLength, unsigned libraryDev, int verify)
 {
     return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, 1, true, libraryLength, libraryDev, verify);
+}
+void * dyo_map_batch_paired_mt(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
+                               unsigned hitsThreshold, unsigned libraryLength, unsigned libraryDev, int verify, unsigned threads)
+{
+    return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, std::max(1u, threads), true, libraryLength, libraryDev, verify);
 }
 void dyo_result_free(void * r) { delete (OResult *)r; }
 u64 dyo_result_n_matches(void * r) { return ((OResult *)r)->matches.size(); }

@@ -29,6 +29,8 @@ def lib():
         l.dyo_ibf_free.argtypes = [P]
         l.dyo_ibf_info.argtypes = [P, P]
         l.dyo_ibf_query.restype = C.c_int; l.dyo_ibf_query.argtypes = [P, P, P, C.c_uint32, C.c_uint16, P]
+        l.dyo_ibf_query_mt.restype = C.c_int; l.dyo_ibf_query_mt.argtypes = [P, P, P, C.c_uint32, C.c_uint16, P, C.c_uint]
+        l.dyo_ibf_attach.restype = P; l.dyo_ibf_attach.argtypes = [P, C.c_uint64, C.c_int]
         l.dyo_ibf_build.restype = C.c_int
         l.dyo_ibf_build.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, P, P, C.c_uint32]
         l.dyo_index_load.restype = P; l.dyo_index_load.argtypes = [C.c_char_p, C.c_uint32]
@@ -38,6 +40,8 @@ def lib():
         l.dyo_map_batch.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint]
         l.dyo_map_batch_paired.restype = P
         l.dyo_map_batch_paired.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int]
+        l.dyo_map_batch_paired_mt.restype = P
+        l.dyo_map_batch_paired_mt.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint]
         l.dyo_result_free.argtypes = [P]
         l.dyo_result_n_matches.restype = C.c_uint64; l.dyo_result_n_matches.argtypes = [P]
         l.dyo_result_n_cigars.restype = C.c_uint64; l.dyo_result_n_cigars.argtypes = [P]
@@ -52,21 +56,27 @@ def _err():
 
 
 class OracleIbf:
-    def __init__(self, path, direct=False):
-        """direct=True: the k-mer direct-addressing filter of -ft kmer_direct (reference src/d_kdx_filter.h)."""
-        self.h = (lib().dyo_kdx_load if direct else lib().dyo_ibf_load)(os.fsencode(path))
+    def __init__(self, path, direct=False, words=None, n_bits=0):
+        """direct=True: the k-mer direct-addressing filter of -ft kmer_direct (reference src/d_kdx_filter.h).
+        words (uint64 array, trailer included) + n_bits: a filter already in memory instead of a file; the array is kept alive here."""
+        if words is not None:
+            assert words.dtype == np.uint64 and words.flags["C_CONTIGUOUS"] and words.size * 64 >= n_bits
+            self._words = words
+            self.h = lib().dyo_ibf_attach(words.ctypes.data, n_bits, 1 if direct else 0)
+        else:
+            self.h = (lib().dyo_kdx_load if direct else lib().dyo_ibf_load)(os.fsencode(path))
         if not self.h:
             raise _err()
         info = np.zeros(6, dtype=np.uint64)
         lib().dyo_ibf_info(self.h, info.ctypes.data)
         self.n_bits, self.n_bins, self.n_hashes, self.kmer_size, self.W, self.n_hash_pos = (int(x) for x in info)
 
-    def query(self, codes, offs, threshold):
+    def query(self, codes, offs, threshold, threads=1):
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         n = offs.size - 1
         masks = np.zeros((n, self.W), dtype=np.uint64)
-        if lib().dyo_ibf_query(self.h, codes.ctypes.data, offs.ctypes.data, n, threshold, masks.ctypes.data):
+        if lib().dyo_ibf_query_mt(self.h, codes.ctypes.data, offs.ctypes.data, n, threshold, masks.ctypes.data, threads):
             raise _err()
         return masks
 
@@ -117,9 +127,9 @@ def map_batch(index, ibf, codes, offs, error_rate, strata_rate=0.0, sensitivity=
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = offs.size - 1
     if paired:
-        h = lib().dyo_map_batch_paired(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
-                                       np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold,
-                                       library_length, library_dev, 1 if verify else 0)
+        h = lib().dyo_map_batch_paired_mt(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
+                                          np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold,
+                                          library_length, library_dev, 1 if verify else 0, threads)
     else:
         h = lib().dyo_map_batch(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
                                 np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold, threads)
