@@ -65,6 +65,7 @@ SYMBOLS = [
     ("dy_ctx_free", None, [_P]),
     ("dy_ctx_sync", C.c_int, [_P]),
     ("dy_ctx_stream", _P, [_P]),
+    ("dy_ctx_set_tuning", C.c_int, [_P, C.c_char_p, C.c_uint64]),
     ("dy_ibf_load", C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     ("dy_ibf_create", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
     ("dy_ibf_add", C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
@@ -143,6 +144,9 @@ class Context:
 
     def sync(self):
         _check(self.lib.dy_ctx_sync(self.h))
+
+    def set_tuning(self, key, value):
+        _check(self.lib.dy_ctx_set_tuning(self.h, key.encode(), int(value)))
 
     def stats(self):
         s = MapStats()

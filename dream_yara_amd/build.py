@@ -41,10 +41,13 @@ def _run(cmd):
 def build(force=False):
     srcs = _sources()
     lib_srcs = [s for s in srcs if not s.endswith(".cpp")]   # headers, .hip and this build script
-    if force or not _newer(LIB, lib_srcs):
-        extra = os.environ.get("DY_HIPCC_FLAGS", "").split()       # tuning experiments only (e.g. -DDY_K3_WAVES=6)
+    extra = os.environ.get("DY_HIPCC_FLAGS", "").split()           # tuning experiments only (e.g. -DDY_K3_WAVES=6)
+    stamp = LIB + ".flags"                                         # a library built with other flags is stale whatever its mtime says
+    built_with = open(stamp).read() if os.path.exists(stamp) else ""
+    if force or not _newer(LIB, lib_srcs) or built_with != " ".join(extra):
         _run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC"] + extra + ["-o", LIB,
               os.path.join(CSRC, "dyhip.hip")])
+        open(stamp, "w").write(" ".join(extra))
     for tool in ("dream_yara_mapper", "dream_yara_build_filter", "dream_yara_update_filter", "dream_yara_indexer"):
         src = os.path.join(CSRC, tool + ".cpp")
         exe = os.path.join(CSRC, tool)

@@ -102,9 +102,34 @@ int deviceCount()
 
 } // namespace
 
+// ctx->counters (u32 slots, zeroed before K3): 0 unused, 1 pool overflow flag, 2 items of the wavefront-per-item list, 3 complex reads,
+// 4 align list, 5 small list, 6 DP list / rescue jobs, 7 bad raw record (dy_finalize_raw), 8 PE child list, 9 PE align list, 10 PE small list,
+// 11 PE heavy pairs, 12 busy-but-not-re-seeded items (= slot 2 + 10, see extendEasyItem), 13 inconsistent record met by k_group_matches,
+// 14-15 the 64-bit raw-match count
+enum { COUNTER_BYTES = 64, COUNTER_BAD_GROUP = 13, COUNTER_POOL64 = 14 };
+
+// Explicit knobs (dy_ctx_set_tuning): which of several result-identical code paths / table sets a context uses.  The defaults are
+// the measured best; the parity tests force the other paths through this, nothing on the mapping path reads the environment.
+struct Tuning
+{
+    u64 sparseSa = 0;           // 1 = keep the on-disk SA sampling (no expanded SA)
+    u64 prefixQ = 12;           // q of the q-mer range table (0 = none); capped by the free HBM at load
+    u64 noIsa = 0;              // 1 = no inverse SA / indexed text (pure LF walk)
+    u64 finalizeBlockMin = 2048;// reads with more raw matches are aggregated by a 1024-thread block
+    u64 finalizeNoKeys = 0;     // 1 = block aggregation sorts indices instead of 128-bit keys
+    u64 peHeavyMin = 256;       // pairs with more unique matches are paired by a wavefront
+    u64 peRescueGlobal = 0;     // 1 = mate-rescue DP rows in global memory instead of LDS
+    u64 ibfNarrow = 0;          // 1 = lane-per-k-mer sweep also for W > 1
+    u64 ibfFullTail = 0;        // 1 = k_ibf_query<7> instead of k_ibf_query_two
+    u64 ibfLdsKb = 12;          // LDS per wave of k_ibf_query_wide
+    u64 ibfDense = 0;           // 1 = no sparse verification in k_ibf_query_wide
+    u64 poolCap = 0;            // initial capacity of the raw-match pool (0 = 2 x items); it grows on overflow either way
+};
+
 struct dy_ctx
 {
     int device = 0;
+    Tuning tune;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     hipStream_t side[2] = {};          // K4's list kernels are latency-bound on a handful of waves each: they run side by side
@@ -335,18 +360,20 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         HIP_CHECK(hipEventRecord(ctx->ev[4], st));
 
         // ---- K3: classify, rank, locate, extend -> raw match pool (grown and re-run on overflow)
-        ctx->counters.reserve(64);
+        ctx->counters.reserve(COUNTER_BYTES);
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
         ctx->hardList.reserve((size_t)nItems * 4 + 64);
-        if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
-        u32 hostCounters[16] = {0};             // [0] pool count, [1] overflow flag, [2] items of the wavefront-per-item list, [12] those of them that are busy but not re-seeded
+        if (ctx->tune.poolCap) { if (!ctx->poolCap) ctx->poolCap = (size_t)ctx->tune.poolCap; }
+        else if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
+        u32 hostCounters[COUNTER_BYTES / 4] = {0};   // layout: see COUNTER_* below
         const int nw = (int)((reads->maxLen + 63) / 64);
+        u64 poolTotal = 0;
         for (;;)
         {
             ctx->pool.reserve(ctx->poolCap * sizeof(RawMatch));
-            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 64, st));
+            HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, COUNTER_BYTES, st));
             HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
-            MatchSink sink; sink.debugFlags = getenv("DY_DEBUG_EXTEND") ? (u32)atoi(getenv("DY_DEBUG_EXTEND")) : 0; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = ctx->counters.as<u32>(); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
+            MatchSink sink; sink.pool = ctx->pool.as<RawMatch>(); sink.poolCount = (unsigned long long *)(ctx->counters.as<u32>() + COUNTER_POOL64); sink.poolCap = (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u);
             sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
             if (nItems)
             {
@@ -356,15 +383,18 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
                 else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink);
                 HIP_CHECK(hipGetLastError());
             }
-            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, 64, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
+            memcpy(&poolTotal, hostCounters + COUNTER_POOL64, 8);
             if (!hostCounters[1]) break;
-            if (hostCounters[0] >= 0xFFFFFFF0u) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
-            ctx->poolCap = (size_t)hostCounters[0] + (size_t)hostCounters[0] / 4 + 1024;
+            // every append was counted, stored or not: the count of the failed pass IS the capacity the batch needs (the extension is
+            // deterministic); + 1/4 only spares a second retry when the caller maps similar batches with the same context
+            if (poolTotal >= 0xFFFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+            ctx->poolCap = (size_t)poolTotal + (size_t)poolTotal / 4 + 1024;
             ctx->stats.pool_retries++;
         }
         HIP_CHECK(hipEventRecord(ctx->ev[5], st));
-        const u32 nPool = hostCounters[0];
+        const u32 nPool = (u32)poolTotal;
         ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12];     // re-seeded items, as the reference counts them
 
         nItemsOut = nItems; nPoolOut = nPool;
@@ -389,8 +419,8 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         HIP_CHECK(hipMemsetAsync(ctx->cursor.p, 0, (size_t)nReads * 4, st));
         ctx->gp.reserve((size_t)nPool * sizeof(RawMatch) + 64);
         if (nPool)
-            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, pool, nPool, ctx->readStart.as<u32>(),
-                               ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>());
+            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, pool, nPool, nReads, ctx->readStart.as<u32>(),
+                               ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>(), ctx->counters.as<u32>() + COUNTER_BAD_GROUP);
         ctx->aux.reserve((size_t)nPool * 16 + 64);
         const size_t setCap = paired ? (size_t)nPool * 3 + nItems : (size_t)nPool * 3;
         res->setCap = setCap;
@@ -399,7 +429,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         takeBuffer(ctx, res->outSet, setCap * sizeof(OutMatch) + 64);
         const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
         // reads with more matches than this are aggregated by a whole 1024-thread block instead of one wavefront (repeats, low-complexity runs)
-        const u32 blockMin = getenv("DY_FINALIZE_BLOCK_MIN") ? (u32)atoi(getenv("DY_FINALIZE_BLOCK_MIN")) : 2048u;
+        const u32 blockMin = (u32)ctx->tune.finalizeBlockMin;
         const u32 hugeBlocks = 512;
         const size_t dpStride = (dpScratchBytes(reads->maxLen, maxMatchErr) + 15) & ~(size_t)15;
         ctx->dp.reserve(dpStride * (finWaves + hugeBlocks) + 64);
@@ -408,9 +438,8 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
         fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
         fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
-        fa.debugFlags = getenv("DY_DEBUG_FINALIZE") ? (u32)atoi(getenv("DY_DEBUG_FINALIZE")) : 0;
         fa.sortKeys = nullptr;
-        if (!paired && !getenv("DY_FINALIZE_NO_KEYS")) { ctx->sortKeys.reserve((size_t)nPool * 48 + 64); fa.sortKeys = ctx->sortKeys.as<u64>(); }
+        if (!paired && !ctx->tune.finalizeNoKeys) { ctx->sortKeys.reserve((size_t)nPool * 48 + 64); fa.sortKeys = ctx->sortKeys.as<u64>(); }
         ctx->complexList.reserve((size_t)nReads * 4 + 64);
         u32 * complexCount = ctx->counters.as<u32>() + 3;          // zeroed with the other counters before K3
         fa.complexList = ctx->complexList.as<u32>(); fa.complexCount = complexCount;
@@ -468,7 +497,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             hipLaunchKernelGGL(k_pe_library, dim3(nBins), dim3(1024), 0, st, V);
             if (nItems)
             {   // pairs whose mates have many unique matches (repeats) are paired by a wavefront each
-                const u32 heavyMin = getenv("DY_PE_HEAVY_MIN") ? (u32)atoi(getenv("DY_PE_HEAVY_MIN")) : 256u;
+                const u32 heavyMin = (u32)ctx->tune.peHeavyMin;
                 ctx->peHeavy.reserve((size_t)nItems * 4 + 64);
                 u32 * heavyCount = ctx->counters.as<u32>() + 11;
                 hipLaunchKernelGGL(k_pe_pair, dim3((nItems + 255) / 256), dim3(256), 0, st, fa, V, heavyMin, ctx->peHeavy.as<u32>(), heavyCount);
@@ -490,7 +519,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                     ctx->peScratch.reserve(stride * rescueWaves + 64);
                     // the DP rows of a wavefront live in LDS when they fit (they do for ordinary libraries: 6 KB per wavefront at 100 bp / sigma 40)
                     const size_t ldsWave = peRescueLdsBytes(reads->maxLen, maxWindow);
-                    const u32 ldsPerWave = ldsWave * 4 <= 60 * 1024 && !getenv("DY_PE_RESCUE_GLOBAL") ? (u32)ldsWave : 0u;
+                    const u32 ldsPerWave = ldsWave * 4 <= 60 * 1024 && !ctx->tune.peRescueGlobal ? (u32)ldsWave : 0u;
                     hipLaunchKernelGGL(k_pe_rescue, dim3(rescueBlocks), dim3(256), (size_t)ldsPerWave * 4, st, fa, V, ctx->peJobs.as<u32>(), jobCount, ctx->peScratch.as<u8>(), stride,
                                        maxWindow, ldsPerWave);
                 }
@@ -616,6 +645,30 @@ int dy_ctx_sync(dy_ctx * ctx)
 }
 
 void * dy_ctx_stream(dy_ctx * ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
+{
+    return guarded([&] {
+        if (!ctx || !key) throw DyError(DY_EINVAL, "dy_ctx_set_tuning: NULL argument");
+        Tuning & t = ctx->tune;
+        const struct { const char * name; u64 * slot; u64 lo, hi; } keys[] = {
+            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"no_isa", &t.noIsa, 0, 1},
+            {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
+            {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
+            {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
+            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull},
+        };
+        for (auto & k : keys)
+            if (!strcmp(k.name, key))
+            {
+                if (value < k.lo || value > k.hi) throw DyError(DY_EINVAL, std::string("dy_ctx_set_tuning: value out of range for ") + key);
+                *k.slot = value;
+                if (k.slot == &t.poolCap) ctx->poolCap = 0;      // takes effect at the next batch
+                return;
+            }
+        throw DyError(DY_EINVAL, std::string("dy_ctx_set_tuning: unknown key ") + key);
+    });
+}
 
 // ---- IBF ----------------------------------------------------------------------------------------------
 static void initGeom(IbfGeom & g, u32 bins, u32 hashes, u32 k, u64 bits)
@@ -901,12 +954,12 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         {
             HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
             const bool longReads = reads->maxLen >= 127 + f->g.kmerSize;
-            if (W == 1 || getenv("DY_IBF_NARROW"))
+            if (W == 1 || ctx->tune.ibfNarrow)
             {
                 const u32 wavesPerBlock = 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
                 const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
-                if (W == 1 && nKmax > 64 && nKmax <= 127 && !getenv("DY_IBF_FULL_TAIL"))
+                if (W == 1 && nKmax > 64 && nKmax <= 127 && !ctx->tune.ibfFullTail)
                     hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
                 else if (!longReads)
@@ -924,9 +977,9 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 const u32 nK = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
                 const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
                 // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
-                const u32 ldsBudget = getenv("DY_IBF_LDS_KB") ? (u32)atoi(getenv("DY_IBF_LDS_KB")) * 1024 : 12 * 1024;
+                const u32 ldsBudget = (u32)ctx->tune.ibfLdsKb * 1024;
                 // sparse verification pays when false candidates are expected in numbers, i.e. at thresholds far below the k-mer count
-                const u32 sparseCap = (nK < 256 && nK <= hashSlots && 4u * threshold <= nK && !getenv("DY_IBF_DENSE")) ? 1024 : 0;
+                const u32 sparseCap = (nK < 256 && nK <= hashSlots && 4u * threshold <= nK && !ctx->tune.ibfDense) ? 1024 : 0;
                 const u32 fixedWords = hashSlots + (sparseCap ? 16 + 128 + sparseCap / 4 : 0);
                 const u32 cacheKmers = ldsBudget > fixedWords * 8 ? std::min<u32>(nK, (u32)((ldsBudget - fixedWords * 8) / (G * 8))) : 0;
                 const size_t perWave = ((size_t)fixedWords + (size_t)cacheKmers * G) * 8;
@@ -975,11 +1028,11 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
         idx->bins = H.bins;
         upload(idx->dBins, H.bins); upload(idx->rank, H.rank); upload(idx->ind, H.ind); upload(idx->valOffset, H.valOffset);
         upload(idx->valContig, H.valContig); upload(idx->contigs, H.contigs); upload(idx->limits, H.limits); upload(idx->drp, H.drp);
-        // expand the sparse SA when it fits comfortably (DY_SPARSE_SA=1 keeps the on-disk sampling, for comparison)
+        // expand the sparse SA when it fits comfortably (tuning key sparse_sa keeps the on-disk sampling, for comparison)
         size_t freeB = 0, totalB = 0;
         HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
         const size_t need = totalRows * (idx->multiContig ? 6 : 4) + 4096;
-        if (!getenv("DY_SPARSE_SA") && need < freeB / 2)
+        if (!ctx->tune.sparseSa && need < freeB / 2)
         {
             idx->saFullOffset.reserve(totalRows * 4 + 64);
             if (idx->multiContig) idx->saFullContig.reserve(totalRows * 2 + 64);
@@ -992,14 +1045,13 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             idx->hasFullSa = true;
         }
-        // q-mer range table: as many levels as fit in a quarter of the free HBM, at most 12 (DY_PREFIX_Q overrides, 0 = off)
+        // q-mer range table: as many levels as fit in a quarter of the free HBM, at most 12 (tuning key prefix_q lowers it, 0 = off)
         {
             HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
-            u32 q = 12;
+            u32 q = (u32)std::min<u64>(ctx->tune.prefixQ, 12);
             u32 nOwned = 0;
             for (u32 b = 0; b < n_bins; ++b) nOwned += H.bins[b].n ? 1 : 0;
             while (q > 0 && ((size_t)std::max(nOwned, 1u) << (2 * q)) * sizeof(uint2) > freeB / 4) --q;
-            if (getenv("DY_PREFIX_Q")) q = std::min<u32>(q, (u32)atoi(getenv("DY_PREFIX_Q")));
             if (q >= 4)
             {
                 const size_t perBin = (size_t)1 << (2 * q);
@@ -1026,9 +1078,9 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
                 idx->prefixQ = q;
             }
         }
-        // inverse SA + indexed text (DY_NO_ISA=1 keeps the pure LF walk, for comparison)
+        // inverse SA + indexed text (tuning key no_isa keeps the pure LF walk, for comparison)
         HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
-        if (idx->hasFullSa && idx->prefixQ && !getenv("DY_NO_ISA") && totalRows * 4 + H.contigs.size() + 4096 < freeB / 4)
+        if (idx->hasFullSa && idx->prefixQ && !ctx->tune.noIsa && totalRows * 4 + H.contigs.size() + 4096 < freeB / 4)
         {
             idx->isa.reserve(totalRows * 4 + 64);
             idx->ftext.reserve(H.contigs.size() + 64);
@@ -1125,7 +1177,10 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
 
         res->readLens = reads->lens;       // for the host-side MAPQ (shared, not copied)
+        u32 badGroup = 0;
+        HIP_CHECK(hipMemcpyAsync(&badGroup, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        if (badGroup) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;
@@ -1421,9 +1476,9 @@ int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const 
         }
         ctx->binOrderRank.reserve((size_t)nBins * 4);
         HIP_CHECK(hipMemcpyAsync(ctx->binOrderRank.p, rank.data(), (size_t)nBins * 4, hipMemcpyHostToDevice, st));
-        ctx->counters.reserve(64);
+        ctx->counters.reserve(COUNTER_BYTES);
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
-        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, 64, st));
+        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, COUNTER_BYTES, st));
         HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
         HIP_CHECK(hipEventRecord(ctx->ev[5], st));
         if (nPool)
@@ -1436,7 +1491,10 @@ int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const 
         runFinalize(ctx, idx, reads, p, res.get(), (const RawMatch *)raw_dev, nPool, 0, maxErr);
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
         res->readLens = reads->lens;
+        u32 badGroup = 0;
+        HIP_CHECK(hipMemcpyAsync(&badGroup, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        if (badGroup) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->stats.ms_finalize = ms;
         ctx->stats.raw_matches = nPool;

@@ -55,7 +55,6 @@ struct FinalizeArgs
     u32 * cigars; u32 cigarStride;
     // reads that need the full aggregation (more than one raw match, or a gapped single match); the others were written by k_finalize_simple
     const u32 * complexList; const u32 * complexCount;
-    u32 debugFlags;               // DY_DEBUG_FINALIZE (timing experiments only): 1 = skip the alignment DP, 2 = skip child passes
     u64 * sortKeys;         // 6 words per raw match (per read: [6 * readStart, ...)), or nullptr
 };
 
@@ -877,7 +876,7 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
                     const u32 pBegin = G::bcast(q < n1 ? a.begin : 0u, pl), pLen = G::bcast(q < n1 ? (u32)a.len : 0u, pl), pErr = G::bcast(q < n1 ? (u32)a.errors : 0u, pl);
                     const u32 pStrand = G::bcast(q < n1 ? (u32)a.strand : 0u, pl), pContig = G::bcast(q < n1 ? (u32)a.contig : 0u, pl);
                     const bool gapped = !(pErr == 0 || (pErr == 1 && pLen == readLen));
-                    if (gapped && !(A.debugFlags & 1))
+                    if (gapped)
                     {   // alignMatches: CIGAR + shrink
                         const BinDesc & bd = A.bins[bin];
                         const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + pContig] + pBegin;
@@ -975,10 +974,10 @@ __global__ __launch_bounds__(G::BLOCK) void k_finalize_t(FinalizeArgs A, u32 min
 __device__ __forceinline__ void writeSingleMatch(const FinalizeArgs & A, u32 read, ReadOut & ro, const RawMatch & a)
 {
     OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
-    if (!(A.debugFlags & 4)) A.outSet[(size_t)ro.setBegin] = om;
+    A.outSet[(size_t)ro.setBegin] = om;
     ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
     ro.mapped = om.length != 0; ro.bestCount = 1; ro.subCount = 0;
-    if (!(A.debugFlags & 16)) A.out[read] = ro;
+    A.out[read] = ro;
 }
 
 // list[count++] = value for the threads that want it, NL lists at once, ONE global atomic per block and list: same-address
@@ -1032,15 +1031,15 @@ __global__ __launch_bounds__(1024) void k_finalize_simple(FinalizeArgs A, u32 * 
                 const bool gapped = !(a.errors == 0 || (a.errors == 1 && a.len == readLen));
                 if (!gapped)
                 {
-                    if (!(A.debugFlags & 8)) A.cigars[ro.cigarBegin] = (readLen << 4) | 0;
+                    A.cigars[ro.cigarBegin] = (readLen << 4) | 0;
                     ro.cigarLen = 1;
                     writeSingleMatch(A, read, ro, a);
                     route = 0;
                 }
-                else if (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
+                else if (readLen <= THREAD_DP_MAX_LEN && a.errors <= THREAD_DP_MAX_E)
                     route = 1;      // alignment needed, but nothing to sort: k_align_check / k_align_single (all lanes busy there)
             }
-            else if (n <= 4 && readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E && !(A.debugFlags & 2))
+            else if (n <= 4 && readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E)
                 route = 2;
         }
     }
@@ -1243,15 +1242,21 @@ __global__ __launch_bounds__(64) void k_finalize_small(FinalizeArgs A, const u32
     }
 }
 
-// readStart-based regrouping of the raw pool
-__global__ void k_group_matches(const RawMatch * __restrict__ pool, u32 nPool, const u32 * __restrict__ readStart, u32 * __restrict__ cursor,
-                                RawMatch * __restrict__ gp)
+// readStart-based regrouping of the raw pool.  A record is only trusted as far as it is consistent with the per-read counts it was
+// appended under: a read id outside the batch or more records of a read than were counted would index readStart / cursor / gp with
+// an arbitrary value (a GPU memory fault aborts the whole process), so such a record raises `bad` and is dropped instead — the host
+// turns the flag into DY_EHIP.  It cannot happen with the kernels in this library; the check costs one load per match.
+__global__ void k_group_matches(const RawMatch * __restrict__ pool, u32 nPool, u32 nReads, const u32 * __restrict__ readStart, u32 * __restrict__ cursor,
+                                RawMatch * __restrict__ gp, u32 * __restrict__ bad)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nPool) return;
     const RawMatch m = pool[i];
-    const u32 dst = readStart[m.read] + atomicAdd(&cursor[m.read], 1u);
-    gp[dst] = m;
+    if (m.read >= nReads) { atomicExch(bad, 1u); return; }
+    const u32 begin = readStart[m.read], end = readStart[m.read + 1];
+    const u32 k = atomicAdd(&cursor[m.read], 1u);
+    if (k >= end - begin) { atomicExch(bad, 1u); return; }
+    gp[begin + k] = m;
 }
 
 } // namespace dy

@@ -382,9 +382,8 @@ struct ItemState
 
 struct MatchSink
 {
-    u32 debugFlags;    // DY_DEBUG_EXTEND (timing experiments only): 1 = stop after locate, 2 = stop before locate
     RawMatch * pool;
-    u32 *      poolCount;
+    unsigned long long * poolCount;   // 64-bit: the count keeps growing past the capacity (it sizes the retry) and must not wrap
     u32        poolCap;
     u32 *      overflow;
     u32 *      readMatchCount;
@@ -496,7 +495,7 @@ __device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 *
         else if (st.nbuf == 1) { st.buf1 = m; st.nbuf = 2; }
         else
         {
-            const u32 slot = atomicAdd(sink.poolCount, 1u);
+            const u64 slot = atomicAdd(sink.poolCount, 1ull);
             if (slot < sink.poolCap) { sink.pool[slot] = m; atomicAdd(&sink.readMatchCount[read], 1u); }
             else atomicExch(sink.overflow, 1u);
         }
@@ -678,16 +677,15 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
             }
         }
         if (!__ballot(have)) break;
-        if (have && !(sink.debugFlags & 2))
+        if (have)
         {   // _extendHitImpl for one SA row (reference src/mapper_extender.h:263-285)
             u32 contig, x;
             if (direct) { contig = directContig; x = directX; } else fmLocate(makeBinView(ix, bin), row, contig, x);
             ++row;
             const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
-            if (clen - x >= seedLen && !(sink.debugFlags & 1))
+            if (clen - x >= seedLen)
                 extendOccurrence<NW>(binContigs, binLimits, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
         }
-        else if (have) ++row;
     }
 }
 
@@ -742,7 +740,6 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                 const u32 off = (cntB - 1 - bestId) * seedLen;
                 const u8 * sq = strand ? seqRc : seq;
                 fmBacktrack(b, seq, len, strand, off, seedLen, E, [&](u32 lo, u32 hi) {
-                    if (sink.debugFlags & 2) return;
                     for (u32 base = lo; base < hi; base += 64)
                     {   // lanes beyond the leaf idle for this step; the loop bound is the same in every lane
                         const u32 row = base + lane;
@@ -752,7 +749,7 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                             u32 contig, x;
                             fmLocate(b, row, contig, x);
                             const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
-                            if (clen - x >= seedLen && !(sink.debugFlags & 1))      // suffixLength >= seedLength
+                            if (clen - x >= seedLen)      // suffixLength >= seedLength
                                 extendOccurrenceT<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, sq, len, off, readErrors,
                                                       [&](u32 matchBegin, u32 matchLen, u32 errors) { got = 1; mBegin = matchBegin; mLen = matchLen; mErrors = errors; mContig = contig; });
                         }
@@ -762,13 +759,13 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                         if (have)
                         {
                             const u32 total = (u32)__popcll(have);
-                            u32 first = 0;
+                            u64 first = 0;
                             if (lane == 0)
                             {
-                                first = atomicAdd(sink.poolCount, total);
+                                first = atomicAdd(sink.poolCount, (unsigned long long)total);
                                 if (first + total <= sink.poolCap) atomicAdd(&sink.readMatchCount[read], total); else atomicExch(sink.overflow, 1u);
                             }
-                            first = __shfl(first, 0, 64);
+                            first = ((u64)__shfl((u32)(first >> 32), 0, 64) << 32) | (u32)__shfl((u32)first, 0, 64);
                             if (got && first + total <= sink.poolCap)
                             {
                                 RawMatch m;
@@ -795,7 +792,7 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
 __device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read, const MatchSink & sink, u32 lane)
 {
     __shared__ u32 waveOff[16];
-    __shared__ u32 blockBase;
+    __shared__ u64 blockBase;
     const u32 wave = threadIdx.x >> 6, nWaves = (blockDim.x + 63) >> 6;
     const u32 cnt = st.nbuf;
     u32 incl = cnt;
@@ -807,10 +804,10 @@ __device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read
     {
         u32 total = 0;
         for (u32 w = 0; w < nWaves; ++w) { const u32 t = waveOff[w]; waveOff[w] = total; total += t; }
-        blockBase = total ? atomicAdd(sink.poolCount, total) : 0;
+        blockBase = total ? atomicAdd(sink.poolCount, (unsigned long long)total) : 0;
     }
     __syncthreads();
-    const u32 first = blockBase + waveOff[wave] + incl - cnt;
+    const u64 first = blockBase + waveOff[wave] + incl - cnt;
     if (cnt >= 1)
     {
         if (first < sink.poolCap) { sink.pool[first] = st.buf0; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);

@@ -726,7 +726,7 @@ __global__ __launch_bounds__(1024) void k_pe_route(FinalizeArgs A, PeView V, con
                 if (m) bin = w * 64 + (u32)(__ffsll((long long)m) - 1);
                 nSel += (u32)__popcll(m);
             }
-            if (nSel == 1 && n >= 2 && n <= SMALL_T && !hasRescue && !(A.debugFlags & 2))
+            if (nSel == 1 && n >= 2 && n <= SMALL_T && !hasRescue)
             {   // a handful of raw matches in the only selected bin: thread-level aggregation (k_pe_finalize_small)
                 const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
                 if (readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E) { complex = false; small = true; }

@@ -264,20 +264,22 @@ public:
         }
         return 0xFFFFFFFFu;
     }
-    static double peResidualWeight(double errorRate) { double p = detPow10(std::min(2.0, 100.0 * errorRate - 7.0)); return p / (1.0 - p); }
-    static double peMatchWeight(double errorRate, double optimalRate) { return (1.0 - errorRate) / detPow10(300.0 * (errorRate - optimalRate)); }
-    static double peMatchProb(double errorRate, double optimalRate, u64 optimalCount, u64 subCount)
+    // getResidualWeight / getMatchWeight / getMatchProb / getLibraryProb — reference src/bits_matches.h:898-966 (std::pow, std::erfc)
+    double pow10Of(double x) const { return opt.detMath ? detPow10(x) : std::pow(10.0, x); }
+    double peResidualWeight(double errorRate) const { double p = pow10Of(std::min(2.0, 100.0 * errorRate - 7.0)); return p / (1.0 - p); }
+    double peMatchWeight(double errorRate, double optimalRate) const { return (1.0 - errorRate) / pow10Of(300.0 * (errorRate - optimalRate)); }
+    double peMatchProb(double errorRate, double optimalRate, u64 optimalCount, u64 subCount) const
     {
         double w = optimalCount * peMatchWeight(optimalRate, optimalRate) + subCount * peMatchWeight(optimalRate + 0.01, optimalRate) + peResidualWeight(optimalRate);
         return peMatchWeight(errorRate, optimalRate) / w;
     }
-    static double libraryProbOf(const Match & one, const Match & two, unsigned mean, unsigned stdDev)
+    double libraryProbOf(const Match & one, const Match & two, unsigned mean, unsigned stdDev) const
     {
         bool proper = orientationProper(one, two) && libraryDeviationOf(one, two, mean) < 6 * stdDev;
         if (!proper) return 0.0009;
         double dev = (double)libraryDeviationOf(one, two, mean);
         double score = dev / stdDev;
-        return std::max(0.001, detErfc(score / 1.41421356237));
+        return std::max(0.001, opt.detMath ? detErfc(score / 1.41421356237) : std::erfc(score / 1.41421356237));
     }
 
     // findProperMates (src/bits_matches.h:819-867): [first,last) into `mates` (sorted by coordinate)

@@ -37,6 +37,10 @@ struct Options
     float    indelRate = 0.25f;
     unsigned libraryLength = 0, libraryDev = 0;
     bool     verifyMatches = true;
+    // NOT a reference option — checker only: evaluate the pairing weights with the device's fixed IEEE sequences (dyo_detmath.hpp) instead of
+    // libm's std::pow / std::erfc as the reference does (src/bits_matches.h:898-966).  tests/test_oracle_pe_math.py shows both give
+    // the same pairing decisions; the default is the reference's libm.
+    bool     detMath = false;
     std::string readGroup = "none";
     std::string version = "1.0.2 []";
     std::string commandLine;

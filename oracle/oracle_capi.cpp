@@ -145,14 +145,14 @@ int dyo_index_build(const char * prefix, const u8 * seqs, const u64 * offs, u32 
 }
 
 static void * mapBatchImpl(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
-                           unsigned hitsThreshold, unsigned threads, bool paired, unsigned libraryLength, unsigned libraryDev, int verify)
+                           unsigned hitsThreshold, unsigned threads, bool paired, unsigned libraryLength, unsigned libraryDev, int verify, bool detMath = false)
 {
     try
     {
         DreamIndex & idx = *(DreamIndex *)idxv;
         Options opt; opt.errorRate = errorRate; opt.strataRate = strataRate; opt.sensitivity = sensitivity; opt.hitsThreshold = hitsThreshold;
         opt.threads = threads; opt.useFilter = ibfv != nullptr;
-        opt.libraryLength = libraryLength; opt.libraryDev = libraryDev; opt.verifyMatches = verify != 0;
+        opt.libraryLength = libraryLength; opt.libraryDev = libraryDev; opt.verifyMatches = verify != 0; opt.detMath = detMath;
         ReadBatch batch = makeBatch(seqs, offs, n);
         DreamMapper mapper(idx, (IBF *)ibfv, opt);
         OResult * R = new OResult;
@@ -193,9 +193,9 @@ void * dyo_map_batch_paired(void * idxv, void * ibfv, const u8 * seqs, const u64
     return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, 1, true, libraryLength, libraryDev, verify);
 }
 void * dyo_map_batch_paired_mt(void * idxv, void * ibfv, const u8 * seqs, const u64 * offs, u32 n, float errorRate, float strataRate, int sensitivity,
-                               unsigned hitsThreshold, unsigned libraryLength, unsigned libraryDev, int verify, unsigned threads)
+                               unsigned hitsThreshold, unsigned libraryLength, unsigned libraryDev, int verify, unsigned threads, int detMath)
 {
-    return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, std::max(1u, threads), true, libraryLength, libraryDev, verify);
+    return mapBatchImpl(idxv, ibfv, seqs, offs, n, errorRate, strataRate, sensitivity, hitsThreshold, std::max(1u, threads), true, libraryLength, libraryDev, verify, detMath != 0);
 }
 void dyo_result_free(void * r) { delete (OResult *)r; }
 u64 dyo_result_n_matches(void * r) { return ((OResult *)r)->matches.size(); }

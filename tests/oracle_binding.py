@@ -41,7 +41,7 @@ def lib():
         l.dyo_map_batch_paired.restype = P
         l.dyo_map_batch_paired.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int]
         l.dyo_map_batch_paired_mt.restype = P
-        l.dyo_map_batch_paired_mt.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint]
+        l.dyo_map_batch_paired_mt.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.c_uint, C.c_int]
         l.dyo_result_free.argtypes = [P]
         l.dyo_result_n_matches.restype = C.c_uint64; l.dyo_result_n_matches.argtypes = [P]
         l.dyo_result_n_cigars.restype = C.c_uint64; l.dyo_result_n_cigars.argtypes = [P]
@@ -120,16 +120,17 @@ class OracleIndex:
 
 
 def map_batch(index, ibf, codes, offs, error_rate, strata_rate=0.0, sensitivity=1, hits_threshold=300, threads=4,
-              paired=False, library_length=0, library_dev=0, verify=True):
+              paired=False, library_length=0, library_dev=0, verify=True, det_math=False):
     """Returns (reads, matches, cigars, stats) as numpy arrays laid out like the device results.
-    paired=True: reads [0,n/2) are the first mates, [n/2,n) the second mates."""
+    paired=True: reads [0,n/2) are the first mates, [n/2,n) the second mates.  det_math=True evaluates the pairing weights with the
+    device's fixed IEEE sequences instead of libm (the reference uses libm: src/bits_matches.h:898-966) — bit-exact pair_prob checks only."""
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
     n = offs.size - 1
     if paired:
         h = lib().dyo_map_batch_paired_mt(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
                                           np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold,
-                                          library_length, library_dev, 1 if verify else 0, threads)
+                                          library_length, library_dev, 1 if verify else 0, threads, 1 if det_math else 0)
     else:
         h = lib().dyo_map_batch(index.h, ibf.h if ibf is not None else None, codes.ctypes.data, offs.ctypes.data, n,
                                 np.float32(error_rate), np.float32(strata_rate), sensitivity, hits_threshold, threads)

@@ -51,6 +51,15 @@ def assert_results_equal(dev, ora):
     assert np.array_equal(d_cigars, o_cigars)
 
 
+def assert_pairing_equal(dev_reads, o_libm, o_det):
+    """Paired-end fields: the oracle evaluates the pairing weights with libm like the reference (src/bits_matches.h:898-966); the
+    device uses fixed IEEE sequences (dy_detmath.h).  Decisions must agree with the libm oracle, the probability to 1e-12 relative;
+    against the oracle run with the same sequences (det_math) the doubles are bit-identical."""
+    assert np.array_equal(dev_reads["paired"], o_libm["paired"])
+    np.testing.assert_allclose(dev_reads["pair_prob"], o_libm["pair_prob"], rtol=1e-12, atol=0)
+    assert np.array_equal(dev_reads["pair_prob"], o_det["pair_prob"])
+
+
 def device_map(dy, ctx, index_dir, n_bins, filter_path, codes, offs, error_rate, strata_rate=0.0, sensitivity=1, read_len_for_thr=None):
     idx = dy.Index(ctx, index_dir, n_bins)
     reads = dy.Reads(ctx, codes, offs)
@@ -271,21 +280,39 @@ def test_map_matches_oracle_on_gold_data(dy, ctx, ob, small_filter, strata):
     oidx.close(); oibf.close()
 
 
-@pytest.mark.parametrize("env", [{"DY_SPARSE_SA": "1"}, {"DY_PREFIX_Q": "0"}, {"DY_NO_ISA": "1"}, {"DY_PREFIX_Q": "6"}])
-def test_map_without_the_device_only_tables(dy, ctx, ob, small_filter, monkeypatch, env):
+@pytest.mark.parametrize("tuning", [{"sparse_sa": 1}, {"prefix_q": 0}, {"no_isa": 1}, {"prefix_q": 6}, {"finalize_block_min": 3, "finalize_no_keys": 1},
+                                    {"ibf_full_tail": 1}])
+def test_map_without_the_device_only_tables(dy, ob, small_filter, tuning):
     """The HBM-sized tables (expanded SA, q-mer ranges, inverse SA + indexed text) only accelerate: with each of them switched
-    off at load time the results stay identical to the oracle (sparse-SA walk, plain LF search, row-range hits)."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    _, codes, offs = read_fasta_codes(READS_FA)
-    codes, offs = codes[: int(offs[2500])], offs[:2501]
-    er = np.float32(3 / 100.0)
-    dev, stats = device_map(dy, ctx, GOLD_INDEX, 64, small_filter, codes, offs, er, np.float32(0.05))
+    off at load time (dy_ctx_set_tuning) the results stay identical to the oracle (sparse-SA walk, plain LF search, row-range
+    hits); likewise the alternative aggregation / sweep kernels."""
+    tctx = dy.Context(0)
+    try:
+        for k, v in tuning.items():
+            tctx.set_tuning(k, v)
+        _, codes, offs = read_fasta_codes(READS_FA)
+        codes, offs = codes[: int(offs[2500])], offs[:2501]
+        er = np.float32(3 / 100.0)
+        dev, stats = device_map(dy, tctx, GOLD_INDEX, 64, small_filter, codes, offs, er, np.float32(0.05))
+    finally:
+        tctx.close()
     oidx = ob.OracleIndex(GOLD_INDEX, 64); oibf = ob.OracleIbf(small_filter)
     o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er, np.float32(0.05))
     assert stats["items"] == ostats["items"] and stats["raw_matches"] == ostats["raw_matches"]
     assert_results_equal(dev, (o_reads, o_matches, o_cigars))
     oidx.close(); oibf.close()
+
+
+def test_tuning_keys_are_validated(dy):
+    tctx = dy.Context(0)
+    try:
+        with pytest.raises(dy.DyError) as e:
+            tctx.set_tuning("no_such_key", 1)
+        assert e.value.code == -1 and "unknown key" in str(e.value)
+        with pytest.raises(dy.DyError):
+            tctx.set_tuning("prefix_q", 13)
+    finally:
+        tctx.close()
 
 
 @pytest.mark.parametrize("gold,extra", [("t1", []), ("tag.t1", ["-sm", "tag", "-s", "10"]), ("rec.t1", ["-sm", "record", "-s", "10"]),
@@ -386,6 +413,41 @@ def test_map_matches_oracle_on_repeats_and_indels(dy, ctx, ob, tmp_path, L, e, s
         assert (o_reads["cigar_len"] > 1).sum() > 0
     oidx.close()
     if oibf: oibf.close()
+
+
+def test_pool_overflow_retry_with_reseeded_reads(dy, ob, tmp_path):
+    """The raw-match pool starts at 64 records (tuning key pool_cap) while the batch yields ~2 million, most of them from re-seeded
+    reads appended 64 at a time by k_extend_hard: every append past the capacity must be dropped and counted, the pool regrown to
+    the counted size and the extension re-run ('pool overflow').  Results and counts equal the oracle's."""
+    L, e = 100, 3
+    rng = np.random.default_rng(L * 1000 + e * 10)
+    n_bins = 6
+    genomes, fam = _repeat_genomes(rng, n_bins, 60000)
+    idx_dir = str(tmp_path / "idx")
+    os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    fpath = str(tmp_path / "f.filter")
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    ob.build_filter(fpath, n_bins, 3, 14, 1 << 24, np.concatenate(genomes), goffs)
+    codes, offs = _sample_reads(rng, genomes, fam, 1500, L, 3)
+    er = np.float32(e / 100.0)
+    tctx = dy.Context(0)
+    try:
+        tctx.set_tuning("pool_cap", 64)
+        dev, stats = device_map(dy, tctx, idx_dir, n_bins, fpath, codes, offs, er)
+        assert stats["pool_retries"] == 1 and stats["hard_items"] > 0 and stats["raw_matches"] > 100000
+        # the grown pool is kept: the same batch again needs no retry and gives the same bytes
+        dev2, stats2 = device_map(dy, tctx, idx_dir, n_bins, fpath, codes, offs, er)
+        assert stats2["pool_retries"] == 0 and stats2["raw_matches"] == stats["raw_matches"]
+        assert dev2[0].tobytes() == dev[0].tobytes() and dev2[1].tobytes() == dev[1].tobytes()
+    finally:
+        tctx.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath)
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er)
+    oidx.close(); oibf.close()
+    assert stats["items"] == ostats["items"] and stats["raw_matches"] == ostats["raw_matches"]
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
 
 
 def test_variable_length_batch_matches_oracle(dy, ctx, ob, tmp_path):
@@ -599,10 +661,10 @@ def test_paired_end_matches_oracle(dy, ctx, ob, tmp_path, use_filter, ll, ld, ve
     oidx = ob.OracleIndex(idx_dir, n_bins)
     oibf = ob.OracleIbf(fpath) if fpath else None
     o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, oibf, codes, offs, er, sr, paired=True, library_length=ll, library_dev=ld, verify=verify)
+    o_det = ob.map_batch(oidx, oibf, codes, offs, er, sr, paired=True, library_length=ll, library_dev=ld, verify=verify, det_math=True)[0]
     assert stats["items"] == ostats["items"]
     assert stats["raw_matches"] == ostats["raw_matches"]
-    assert np.array_equal(dev[0]["paired"], o_reads["paired"])
-    assert np.array_equal(dev[0]["pair_prob"], o_reads["pair_prob"])          # bit-identical doubles (dy_detmath.h)
+    assert_pairing_equal(dev[0], o_reads, o_det)
     assert_results_equal(dev, (o_reads, o_matches, o_cigars))
     se_reads = ob.map_batch(oidx, oibf, codes, offs, er, sr)[0]
     rescued = int(o_reads["mapped"].sum()) - int(se_reads["mapped"].sum())
@@ -668,12 +730,12 @@ def test_paired_end_on_repeat_families_matches_oracle(dy, ctx, ob, tmp_path):
     stats = ctx.stats()
     res.close(); reads.close(); idx.close()
     oidx = ob.OracleIndex(idx_dir, n_bins)
-    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, None, codes, offs, er, sr, paired=True)
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, None, codes, offs, er, sr, paired=True, threads=8)
+    o_det = ob.map_batch(oidx, None, codes, offs, er, sr, paired=True, threads=8, det_math=True)[0]
     oidx.close()
     assert stats["raw_matches"] == ostats["raw_matches"]
     assert stats["hard_items"] > 50
-    assert np.array_equal(dev[0]["paired"], o_reads["paired"])
-    assert np.array_equal(dev[0]["pair_prob"], o_reads["pair_prob"])
+    assert_pairing_equal(dev[0], o_reads, o_det)
     assert_results_equal(dev, (o_reads, o_matches, o_cigars))
     assert (o_reads["best_count"] > 100).sum() > 100           # the repeat reads really carry hundreds of co-optimal locations
 
