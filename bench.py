@@ -146,8 +146,6 @@ def main():
 
     t0 = time.time()
     if args.paired:
-        if args.shard == "bins":
-            raise SystemExit("--paired needs --shard reads (pairing over sharded bins is not implemented)")
         codes, offs, ptruth = synth.simulate_pairs(genomes, wl["reads"] // 2, wl["L"], seed=shard_seed(4, rank))
         truth = np.zeros(wl["reads"], dtype=[("bin", "<u4")]); truth["bin"] = np.concatenate([ptruth["bin"], ptruth["bin"]])
     else:

@@ -98,14 +98,17 @@ SYMBOLS = [
     ("dy_kdx_create", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("dy_kdx_load", C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     ("dy_index_load_sharded", C.c_int, [_P, C.c_char_p, C.c_uint32, _P, C.POINTER(_P)]),
-    ("dy_shard_plan", C.c_int, [_P, _P, C.c_uint32, _P, _P, _P]),
+    ("dy_shard_plan", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]),
     ("dy_shard_pack", C.c_int, [_P, _P, _P, _P, _P, _P]),
     ("dy_reads_from_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
+    ("dy_reads_from_device_paired", C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(_P)]),
+    ("dy_pe_items_pack", C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
     ("dy_map_bins", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.POINTER(C.c_uint64)]),
     ("dy_raw_pack", C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
-    ("dy_finalize_raw", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.c_uint64, _P, C.POINTER(_P)]),
+    ("dy_finalize_raw", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(_P)]),
 ]
 RAW_MATCH_BYTES = 16
+PE_ITEM_BYTES = 40
 
 _lib = None
 
@@ -232,12 +235,17 @@ def threshold(error_rate, kmer_size, read_len):
 
 class Reads:
     @classmethod
-    def from_device(cls, ctx, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins):
-        """A batch from device buffers in dy_shard_pack's layout (raw device addresses)."""
+    def from_device(cls, ctx, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, paired_seg_starts=None):
+        """A batch from device buffers in dy_shard_pack's layout (raw device addresses).  paired_seg_starts (n_ranks + 1 arrival
+        offsets): a paired job, re-ordered to [first mates | second mates] (dy_reads_from_device_paired)."""
         self = cls.__new__(cls)
         self.ctx, self.lib, self.n = ctx, ctx.lib, n_reads
         h = _P()
-        _check(self.lib.dy_reads_from_device(ctx.h, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, C.byref(h)))
+        if paired_seg_starts is not None:
+            seg = np.ascontiguousarray(paired_seg_starts, dtype=np.uint32)
+            _check(self.lib.dy_reads_from_device_paired(ctx.h, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, seg.size - 1, seg.ctypes.data, C.byref(h)))
+        else:
+            _check(self.lib.dy_reads_from_device(ctx.h, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, C.byref(h)))
         self.h = h
         return self
 
@@ -336,12 +344,12 @@ def map_reads(ctx, index, reads, params, asynchronous=False):
     return Result(ctx, h, reads.n)
 
 
-def shard_plan(ctx, reads, owner_masks):
+def shard_plan(ctx, reads, owner_masks, paired=False):
     """owner_masks: (n_ranks, W) uint64.  Returns (reads per destination rank, bases per destination rank)."""
     owner_masks = np.ascontiguousarray(owner_masks, dtype=np.uint64)
     n_ranks = owner_masks.shape[0]
     n_to = np.zeros(n_ranks, np.uint32); b_to = np.zeros(n_ranks, np.uint64)
-    _check(ctx.lib.dy_shard_plan(ctx.h, reads.h, n_ranks, owner_masks.ctypes.data, n_to.ctypes.data, b_to.ctypes.data))
+    _check(ctx.lib.dy_shard_plan(ctx.h, reads.h, n_ranks, owner_masks.ctypes.data, 1 if paired else 0, n_to.ctypes.data, b_to.ctypes.data))
     return n_to, b_to
 
 
@@ -365,10 +373,18 @@ def raw_pack(ctx, seg_starts, ids_ptr, raw_out_ptr):
     return n_to
 
 
-def finalize_raw(ctx, index, reads, params, raw_ptr, n_raw, bin_loads):
+def pe_items_pack(ctx, seg_starts, ids_ptr, items_out_ptr):
+    seg_starts = np.ascontiguousarray(seg_starts, dtype=np.uint32)
+    n_ranks = seg_starts.size - 1
+    n_to = np.zeros(n_ranks, np.uint64)
+    _check(ctx.lib.dy_pe_items_pack(ctx.h, n_ranks, seg_starts.ctypes.data, ids_ptr, items_out_ptr, n_to.ctypes.data))
+    return n_to
+
+
+def finalize_raw(ctx, index, reads, params, raw_ptr, n_raw, bin_loads, pe_items_ptr=None, n_pe_items=0):
     bin_loads = np.ascontiguousarray(bin_loads, dtype=np.uint32)
     h = _P()
-    _check(ctx.lib.dy_finalize_raw(ctx.h, index.h, reads.h, C.byref(params), raw_ptr, n_raw, bin_loads.ctypes.data, C.byref(h)))
+    _check(ctx.lib.dy_finalize_raw(ctx.h, index.h, reads.h, C.byref(params), raw_ptr, n_raw, pe_items_ptr, n_pe_items, bin_loads.ctypes.data, C.byref(h)))
     return Result(ctx, h, reads.n)
 
 

@@ -150,6 +150,7 @@ struct dy_ctx
     // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
     const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
     u32 lastRaw = 0; bool rawValid = false;
+    u32 lastItems = 0; bool lastPaired = false; DevBuf shOrig;      // paired dy_map_bins: item count and the batch's arrival indices for dy_raw_pack / dy_pe_items_pack
 };
 
 // result buffers are recycled through the context: take the smallest spare that is large enough, else allocate
@@ -204,6 +205,8 @@ struct dy_reads
     u32 maskW = 0;       // words per read currently held in masks (0 = none)
     bool recycle = false; // buffers came from / go back to the context's spare pool (batches built per step by dy_reads_from_device)
     u32 maskBins = 0;
+    DevBuf orig;          // dy_reads_from_device_paired: arrival index of every read (the batch is re-ordered to [first mates | second mates])
+    bool pairLayout = false;
 };
 
 struct dy_index
@@ -296,13 +299,11 @@ static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & r
                        ctx->itemBin.as<u16>(), S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>());
 }
 
-// Work list + K2 + K3: (read,bin) items of the masks on `reads` -> raw matches in ctx->pool, per-read counts in ctx->readMatchCount.
-static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, u32 S0, u32 & nItemsOut, u32 & nPoolOut)
+// Work list (bin-major): (read,bin) items of the masks on `reads` -> ctx->itemRead / itemBin / binStart (+ the local sortedBins() rank).
+static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
 {
         hipStream_t st = ctx->stream;
-        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
-        // ---- work list (bin-major)
-        HIP_CHECK(hipEventRecord(ctx->ev[2], st));
+        const u32 nReads = reads->n, W = (nBins + 63) / 64;
         const u32 nWaves = (nReads + 63) / 64;
         const size_t nCells = (size_t)nBins * nWaves;
         ctx->waveCounts.reserve((nCells + 1) * 4); ctx->waveOffsets.reserve((nCells + 1) * 4);
@@ -321,11 +322,21 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (ctx->ibfTimingPending) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; ctx->ibfTimingPending = false; }
-        ctx->stats.items = nItems;
         ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
         if (nItems)
             hipLaunchKernelGGL(k_items_scatter, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins,
                                ctx->waveOffsets.as<u32>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>());
+        return nItems;
+}
+
+// Work list + K2 + K3: (read,bin) items of the masks on `reads` -> raw matches in ctx->pool, per-read counts in ctx->readMatchCount.
+static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, u32 S0, u32 & nItemsOut, u32 & nPoolOut)
+{
+        hipStream_t st = ctx->stream;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size();
+        HIP_CHECK(hipEventRecord(ctx->ev[2], st));
+        const u32 nItems = buildWorkList(ctx, reads, nBins);
+        ctx->stats.items = nItems;
         HIP_CHECK(hipEventRecord(ctx->ev[3], st));
 
         // ---- K2: exact search of the round-0 seeds
@@ -401,8 +412,13 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
 }
 
 // Group raw matches by read (counts in ctx->readMatchCount) and run the per-read aggregation (K4 / paired-end stages).
+// Paired-end: the bin-local stages (child, library, pairing, rescue — the reference's child mapper, src/mapper.h:826-1172) run where the
+// bin's FM index lives (PE_OWNER) and the per-read merge over the bins (copyMatches / copyCigars / main mapper, src/d_mapper.h:127-245)
+// where the read lives (PE_HOME); one GPU does both.  PE_OWNER alone: `res` may be NULL.  PE_HOME alone: the caller has filled
+// ctx->peItems / peHasRescue from the owners' records and the work list of the home reads is in place.
+enum { PE_OWNER = 1, PE_HOME = 2 };
 static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, dy_result * res, const RawMatch * pool, u32 nPool,
-                        u32 nItems, u32 maxMatchErr)
+                        u32 nItems, u32 maxMatchErr, u32 peStages = PE_OWNER | PE_HOME)
 {
         hipStream_t st = ctx->stream;
         const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
@@ -422,11 +438,15 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, pool, nPool, nReads, ctx->readStart.as<u32>(),
                                ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>(), ctx->counters.as<u32>() + COUNTER_BAD_GROUP);
         ctx->aux.reserve((size_t)nPool * 16 + 64);
+        const bool home = !paired || (peStages & PE_HOME), owner = !paired || (peStages & PE_OWNER);
         const size_t setCap = paired ? (size_t)nPool * 3 + nItems : (size_t)nPool * 3;
-        res->setCap = setCap;
-        ctx->marr.reserve(setCap * sizeof(RawMatch) + 64);
-        ctx->maux.reserve(setCap * 2 * 4 + 64);
-        takeBuffer(ctx, res->outSet, setCap * sizeof(OutMatch) + 64);
+        if (home)
+        {
+            res->setCap = setCap;
+            ctx->marr.reserve(setCap * sizeof(RawMatch) + 64);
+            ctx->maux.reserve(setCap * 2 * 4 + 64);
+            takeBuffer(ctx, res->outSet, setCap * sizeof(OutMatch) + 64);
+        }
         const u32 finBlocks = 256 * 8, finWaves = finBlocks * 4;
         // reads with more matches than this are aggregated by a whole 1024-thread block instead of one wavefront (repeats, low-complexity runs)
         const u32 blockMin = (u32)ctx->tune.finalizeBlockMin;
@@ -437,7 +457,8 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         fa.gp = ctx->gp.as<RawMatch>(); fa.readStart = ctx->readStart.as<u32>(); fa.readOffs = rv.offs; fa.readSeqs = rv.seqs; fa.readSeqsRc = rv.seqsRc; fa.nReads = nReads;
         fa.bins = ix.bins; fa.contigs = ix.contigs; fa.limits = ix.limits; fa.binOrderRank = ctx->binOrderRank.as<u32>(); fa.strataRate = p->strata_rate; fa.errorRate = p->error_rate;
         fa.aux = ctx->aux.as<u32>(); fa.marr = ctx->marr.as<RawMatch>(); fa.maux = ctx->maux.as<u32>(); fa.dpScratch = ctx->dp.as<u8>(); fa.dpStride = dpStride;
-        fa.out = res->out.as<ReadOut>(); fa.outSet = res->outSet.as<OutMatch>(); fa.cigars = res->cigars.as<u32>(); fa.cigarStride = res->cigarStride;
+        fa.out = home ? res->out.as<ReadOut>() : nullptr; fa.outSet = home ? res->outSet.as<OutMatch>() : nullptr;
+        fa.cigars = home ? res->cigars.as<u32>() : nullptr; fa.cigarStride = home ? res->cigarStride : 0;
         fa.sortKeys = nullptr;
         if (!paired && !ctx->tune.finalizeNoKeys) { ctx->sortKeys.reserve((size_t)nPool * 48 + 64); fa.sortKeys = ctx->sortKeys.as<u64>(); }
         ctx->complexList.reserve((size_t)nReads * 4 + 64);
@@ -482,14 +503,19 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             ctx->peLib.reserve((size_t)nBins * sizeof(PeLibrary) + 64);
             ctx->peLens.reserve((size_t)nItems * 4 + 64); ctx->peIdx.reserve((size_t)nItems * 4 + 64);
             ctx->peHasRescue.reserve((size_t)nReads * 4 + 64); ctx->peJobs.reserve((size_t)nItems * 4 + 64);
-            HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
-            HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
+            if (owner)
+            {
+                HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
+                HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
+            }
             PeView V;
             V.items = ctx->peItems.as<PeItem>(); V.u2 = ctx->peU2.as<RawMatch>(); V.itemRead = ctx->itemRead.as<u32>(); V.itemBin = ctx->itemBin.as<u16>();
             V.binStart = ctx->binStart.as<u32>(); V.masks = reads->masks.as<u64>(); V.W = W; V.nBins = nBins; V.nPairs = nReads / 2; V.nItems = nItems;
             V.lib = ctx->peLib.as<PeLibrary>(); V.libLens = ctx->peLens.as<u32>(); V.libIdx = ctx->peIdx.as<u32>();
             V.optLibLength = p->library_length; V.optLibDev = p->library_dev; V.verify = p->verify_matches;
             V.errorRate = p->error_rate; V.indelRate = p->indel_rate; V.strataRate = p->strata_rate; V.readHasRescue = ctx->peHasRescue.as<u32>();
+            if (owner)
+            {
             ctx->dpList.reserve((size_t)nReads * 4 + 64);         // reads with more than one raw match (list of k_pe_child)
             u32 * childCount = ctx->counters.as<u32>() + 8;
             hipLaunchKernelGGL(k_pe_child_simple, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, V, ctx->dpList.as<u32>(), childCount);
@@ -524,6 +550,9 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                                        maxWindow, ldsPerWave);
                 }
             }
+            }
+            if (home)
+            {
             // room per read in the main mapper's match array: 3 per raw match + one per selected bin (a rescued mate)
             ctx->peMCounts.reserve((size_t)(nReads + 1) * 4 + 64); ctx->peMStart.reserve((size_t)(nReads + 1) * 4 + 64);
             hipLaunchKernelGGL(k_pe_mcounts, dim3((nReads + 1 + 255) / 256), dim3(256), 0, st, ctx->readMatchCount.as<u32>(), reads->masks.as<u64>(), W, nReads, ctx->peMCounts.as<u32>());
@@ -564,6 +593,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             hipLaunchKernelGGL(k_pe_finalize, dim3(finBlocks), dim3(256), 0, st, fa, V, ctx->peMStart.as<u32>());
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
+            }
         }
         HIP_CHECK(hipGetLastError());
 }
@@ -577,6 +607,14 @@ static unsigned mapqOf(unsigned errors, unsigned readLen, u64 best, u64 sub)
     double w = best * matchWeight(rate, rate) + sub * matchWeight(rate + 0.01, rate) + residualWeight(rate);
     double prob = matchWeight(rate, rate) / w;
     return (unsigned)std::round(-10.0 * std::log10(1.0 - std::min(prob, 0.9999999)));
+}
+
+// a rescued mate may carry up to maxErrors + maxIndels 'errors' (score / -999, reference src/find_verifier.h:112-139)
+static u32 maxMatchErrorsOf(const dy_reads * reads, const dy_params * p, u32 maxErr)
+{
+    if (!(p->paired && p->verify_matches)) return maxErr;
+    const u32 mi = (u32)((float)reads->maxLen * p->indel_rate);
+    return std::min<u32>(MAX_ERRORS, maxErr + std::min<u32>(mi, MAX_ERRORS));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -935,7 +973,7 @@ void dy_reads_free(dy_reads * r)
 {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
-    if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); }
+    if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); giveBuffer(r->ctx, r->orig); }
     delete r;
 }
 
@@ -1161,9 +1199,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
             hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(nReads / 2) * W + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nReads / 2, W);
 
         std::unique_ptr<dy_result> res(new dy_result);
-        // a rescued mate may carry up to maxErrors + maxIndels 'errors' (score / -999, reference src/find_verifier.h:112-139)
-        u32 maxMatchErr = maxErr;
-        if (p->paired && p->verify_matches) { u32 mi = (u32)((float)reads->maxLen * p->indel_rate); maxMatchErr = std::min<u32>(MAX_ERRORS, maxErr + std::min<u32>(mi, MAX_ERRORS)); }
+        const u32 maxMatchErr = maxMatchErrorsOf(reads, p, maxErr);
         res->ctx = ctx; res->nReads = nReads; res->cigarStride = 2 * maxMatchErr + 1;
         takeBuffer(ctx, res->out, (size_t)nReads * sizeof(ReadOut) + 64);
         takeBuffer(ctx, res->cigars, (size_t)nReads * res->cigarStride * 4 + 64);
@@ -1291,7 +1327,7 @@ int dy_map_get_stats(const dy_ctx * ctx, dy_map_stats * s)
 }
 
 // ---- bins sharded over ranks --------------------------------------------------------------------------
-int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const uint64_t * owner_masks, uint32_t * n_reads_to, uint64_t * n_bases_to)
+int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const uint64_t * owner_masks, uint32_t paired, uint32_t * n_reads_to, uint64_t * n_bases_to)
 {
     return guarded([&] {
         if (!ctx || !reads || !owner_masks || !n_reads_to || !n_bases_to) throw DyError(DY_EINVAL, "dy_shard_plan: NULL argument");
@@ -1302,6 +1338,9 @@ int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const 
         const u32 n = reads->n, W = reads->maskW;
         const u64 total = (u64)n_ranks * n;
         if (total + 1 > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "ranks x reads too large for one plan");
+        if (paired && (n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
+        // the four sequences of a pair vote together (reference src/d_mapper.h:350-358): both mates go wherever either is selected
+        if (paired && n) hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(n / 2) * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), n / 2, W);
         ctx->planReads = nullptr;
         ctx->shOwner.reserve((size_t)n_ranks * W * 8 + 64);
         HIP_CHECK(hipMemcpyAsync(ctx->shOwner.p, owner_masks, (size_t)n_ranks * W * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1345,42 +1384,85 @@ int dy_shard_pack(dy_ctx * ctx, const dy_reads * reads, void * ids_dev, void * l
     });
 }
 
-int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
-                         uint32_t n_bins, dy_reads ** out)
+// shared body of dy_reads_from_device / dy_reads_from_device_paired (seg_starts != NULL: paired layout)
+static void readsFromDevice(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
+                            uint32_t n_bins, uint32_t n_ranks, const uint32_t * seg_starts, dy_reads ** out)
 {
-    return guarded([&] {
         if (!ctx || !out || (n_reads && (!lens_dev || !masks_dev)) || (n_bases && !seqs_dev)) throw DyError(DY_EINVAL, "dy_reads_from_device: NULL argument");
         if (n_reads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
         if (n_bins == 0 || n_bins > 65535) throw DyError(DY_EINVAL, "number of bins out of range");
+        const bool paired = seg_starts != nullptr;
+        if (paired)
+        {
+            if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
+            if (seg_starts[0] != 0 || seg_starts[n_ranks] != n_reads) throw DyError(DY_EINVAL, "seg_starts must run from 0 to n_reads");
+            for (u32 r = 0; r < n_ranks; ++r)
+                if (seg_starts[r + 1] < seg_starts[r] || ((seg_starts[r + 1] - seg_starts[r]) & 1))
+                    throw DyError(DY_EINVAL, "every source segment of a paired batch holds an even number of reads (first mates, then second mates)");
+        }
         HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
         std::unique_ptr<dy_reads> r(new dy_reads);
         r->ctx = ctx; r->n = n_reads; r->totalBases = n_bases;
-        r->recycle = true;
+        r->recycle = true; r->pairLayout = paired;
         takeBuffer(ctx, r->seqs, n_bases + 64); takeBuffer(ctx, r->seqsRc, n_bases + 64);
         takeBuffer(ctx, r->offs, (size_t)(n_reads + 1) * 8);
         const u32 W = (n_bins + 63) / 64;
         takeBuffer(ctx, r->masks, (size_t)n_reads * W * 8 + 8);
         r->maskW = W; r->maskBins = n_bins;
-        if (n_bases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs_dev, n_bases, hipMemcpyDeviceToDevice, ctx->stream));
-        if (n_reads) HIP_CHECK(hipMemcpyAsync(r->masks.p, masks_dev, (size_t)n_reads * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
         ctx->shLen.reserve((size_t)(n_reads + 1) * 8);
-        hipLaunchKernelGGL(k_widen_lens, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)lens_dev, n_reads, ctx->shLen.as<u64>());
-        exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
-        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
+        ctx->planReads = nullptr;        // shLen is reused
+        if (!paired)
+        {
+            if (n_bases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs_dev, n_bases, hipMemcpyDeviceToDevice, st));
+            if (n_reads) HIP_CHECK(hipMemcpyAsync(r->masks.p, masks_dev, (size_t)n_reads * W * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_widen_lens, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, st, (const u32 *)lens_dev, n_reads, ctx->shLen.as<u64>());
+            exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
+        }
+        else
+        {
+            takeBuffer(ctx, r->orig, (size_t)n_reads * 4 + 64);
+            ctx->shSeg.reserve(64 * 4 * 3 + 64);
+            HIP_CHECK(hipMemcpyAsync(ctx->shSeg.p, seg_starts, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, st));
+            ctx->shLenOff.reserve((size_t)(n_reads + 1) * 8);
+            if (n_reads) hipLaunchKernelGGL(k_pair_layout, dim3((n_reads + 255) / 256), dim3(256), 0, st, ctx->shSeg.as<u32>(), n_ranks, n_reads, r->orig.as<u32>());
+            // offsets of the arrival order (shLenOff) and of the new order (r->offs)
+            hipLaunchKernelGGL(k_widen_lens, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, st, (const u32 *)lens_dev, n_reads, ctx->shLen.as<u64>());
+            exclusiveSum(ctx, ctx->shLen.as<u64>(), ctx->shLenOff.as<u64>(), (size_t)n_reads + 1);
+            hipLaunchKernelGGL(k_permute_scalars, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, st, r->orig.as<u32>(), n_reads, W, (const u32 *)lens_dev, (const u64 *)masks_dev,
+                               ctx->shLen.as<u64>(), r->masks.as<u64>());
+            exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
+            if (n_reads) hipLaunchKernelGGL(k_permute_bases, dim3(std::min<u32>((n_reads + 3) / 4, 8192u)), dim3(256), 0, st, r->orig.as<u32>(), n_reads, ctx->shLenOff.as<u64>(),
+                                            (const u8 *)seqs_dev, r->offs.as<u64>(), r->seqs.as<u8>());
+        }
+        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, st, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
         HIP_CHECK(hipGetLastError());
-        ctx->planReads = nullptr;        // shLen was reused
         // length statistics on the device (the lengths themselves stay there: a batch built this way is searched, never reported)
         unsigned long long hostStats[3] = {0, 0, ~0ull};
         ctx->shTotals.reserve(64);
-        HIP_CHECK(hipMemcpyAsync(ctx->shTotals.p, hostStats, 24, hipMemcpyHostToDevice, ctx->stream));
-        if (n_reads) hipLaunchKernelGGL(k_lens_stats, dim3(256), dim3(256), 0, ctx->stream, (const u32 *)lens_dev, n_reads, ctx->shTotals.as<unsigned long long>());
-        HIP_CHECK(hipMemcpyAsync(hostStats, ctx->shTotals.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(ctx->shTotals.p, hostStats, 24, hipMemcpyHostToDevice, st));
+        if (n_reads) hipLaunchKernelGGL(k_lens_stats, dim3(256), dim3(256), 0, st, (const u32 *)lens_dev, n_reads, ctx->shTotals.as<unsigned long long>());
+        HIP_CHECK(hipMemcpyAsync(hostStats, ctx->shTotals.p, 24, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
         const u64 sum = hostStats[0]; const u32 mx = (u32)hostStats[1], mn = (u32)hostStats[2];
         if (mx > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");
         if (sum != n_bases) throw DyError(DY_EINVAL, "dy_reads_from_device: lengths do not add up to n_bases");
         r->maxLen = mx; r->minLen = n_reads ? mn : 0;
         *out = r.release();
+}
+
+int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
+                         uint32_t n_bins, dy_reads ** out)
+{
+    return guarded([&] { readsFromDevice(ctx, seqs_dev, lens_dev, masks_dev, n_reads, n_bases, n_bins, 0, nullptr, out); });
+}
+
+int dy_reads_from_device_paired(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
+                                uint32_t n_bins, uint32_t n_ranks, const uint32_t * seg_starts, dy_reads ** out)
+{
+    return guarded([&] {
+        if (!seg_starts) throw DyError(DY_EINVAL, "dy_reads_from_device_paired: seg_starts is NULL");
+        readsFromDevice(ctx, seqs_dev, lens_dev, masks_dev, n_reads, n_bases, n_bins, n_ranks, seg_starts, out);
     });
 }
 
@@ -1390,8 +1472,9 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
         if (!ctx || !idx || !reads || !p || !bin_loads || !n_raw) throw DyError(DY_EINVAL, "dy_map_bins: NULL argument");
         if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
         if (p->sensitivity > 1) throw DyError(DY_EUNSUPPORTED, "sensitivity 'full' (edit-distance seeds) is not implemented");
-        if (p->paired) throw DyError(DY_EUNSUPPORTED, "paired-end mapping over sharded bins is not implemented");
         if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
+        const bool paired = p->paired != 0;
+        if (paired && !reads->pairLayout) throw DyError(DY_EINVAL, "a paired dy_map_bins needs a batch built by dy_reads_from_device_paired");
         HIP_CHECK(hipSetDevice(ctx->device));
         const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
         if (reads->maskW != W || reads->maskBins != nBins) throw DyError(DY_EINVAL, "the reads carry no bin masks for this index");
@@ -1399,7 +1482,7 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
         const u32 S0 = seedCountOf(maxErr, 0);
         if (S0 > MAX_SEEDS) throw DyError(DY_EUNSUPPORTED, "more than 32 seeds per read (read length x error rate too large)");
         ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
-        ctx->rawValid = false; ctx->lastRaw = 0;
+        ctx->rawValid = false; ctx->lastRaw = 0; ctx->lastItems = 0; ctx->lastPaired = paired;
         for (u32 b = 0; b < nBins; ++b) bin_loads[b] = 0;
         *n_raw = 0;
         if (!nReads) { ctx->rawValid = true; return; }
@@ -1407,17 +1490,45 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
         hipLaunchKernelGGL(k_and_masks, dim3((u32)(((u64)nReads * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), nReads, W, idx->dOwnedMask.as<u64>());
         u32 nItems = 0, nPool = 0;
         runSearchExtend(ctx, idx, reads, p, S0, nItems, nPool);
+        if (paired)
+        {   // the child mapper's pairing stages are bin-local: they run here, on the owner of the bin (reference src/mapper.h:927-1172)
+            runFinalize(ctx, idx, reads, p, nullptr, ctx->pool.as<RawMatch>(), nPool, nItems, maxMatchErrorsOf(reads, p, maxErr), PE_OWNER);
+            ctx->shOrig.reserve((size_t)nReads * 4 + 64);
+            HIP_CHECK(hipMemcpyAsync(ctx->shOrig.p, reads->orig.p, (size_t)nReads * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         std::vector<u32> starts(nBins + 1);
         HIP_CHECK(hipMemcpyAsync(starts.data(), ctx->binStart.p, (size_t)(nBins + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        u32 badGroup = 0;
+        HIP_CHECK(hipMemcpyAsync(&badGroup, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (badGroup) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
         for (u32 b = 0; b < nBins; ++b) bin_loads[b] = starts[b + 1] - starts[b];
         *n_raw = nPool;
-        ctx->lastRaw = nPool; ctx->rawValid = true;
+        ctx->lastRaw = nPool; ctx->lastItems = nItems; ctx->rawValid = true;
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_extend = ms;
     });
+}
+
+// shared by dy_raw_pack / dy_pe_items_pack: per-source counts -> host, cursors -> device
+static void segCursors(dy_ctx * ctx, u32 n_ranks, const u32 * seg_starts, u32 *& segDev, u32 *& counts, u32 *& cursors)
+{
+    ctx->shSeg.reserve(64 * 4 * 3 + 64);
+    segDev = ctx->shSeg.as<u32>(); counts = segDev + 80; cursors = segDev + 160;
+    HIP_CHECK(hipMemcpyAsync(segDev, seg_starts, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(counts, 0, 64 * 4, ctx->stream));
+}
+static u32 segCountsToCursors(dy_ctx * ctx, u32 n_ranks, u32 * counts, u32 * cursors, uint64_t * n_to)
+{
+    u32 hostCounts[64];
+    HIP_CHECK(hipMemcpyAsync(hostCounts, counts, (size_t)n_ranks * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    u32 hostCursor[64]; u32 acc = 0;
+    for (u32 s = 0; s < n_ranks; ++s) { hostCursor[s] = acc; acc += hostCounts[s]; n_to[s] = hostCounts[s]; }
+    HIP_CHECK(hipMemcpyAsync(cursors, hostCursor, (size_t)n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
+    return acc;
 }
 
 int dy_raw_pack(dy_ctx * ctx, uint32_t n_ranks, const uint32_t * seg_starts, const void * ids_dev, void * raw_out_dev, uint64_t * n_raw_to)
@@ -1432,40 +1543,84 @@ int dy_raw_pack(dy_ctx * ctx, uint32_t n_ranks, const uint32_t * seg_starts, con
         for (u32 s = 0; s < n_ranks; ++s) n_raw_to[s] = 0;
         if (!n) return;
         if (!ids_dev || !raw_out_dev) throw DyError(DY_EINVAL, "dy_raw_pack: NULL buffer");
-        ctx->shSeg.reserve(64 * 4 * 3 + 64);
-        u32 * segDev = ctx->shSeg.as<u32>(), * counts = segDev + 80, * cursors = segDev + 160;
-        HIP_CHECK(hipMemcpyAsync(segDev, seg_starts, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIP_CHECK(hipMemsetAsync(counts, 0, 64 * 4, ctx->stream));
-        hipLaunchKernelGGL(k_raw_seg_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, counts);
-        u32 hostCounts[64];
-        HIP_CHECK(hipMemcpyAsync(hostCounts, counts, (size_t)n_ranks * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        u32 hostCursor[64]; u32 acc = 0;
-        for (u32 s = 0; s < n_ranks; ++s) { hostCursor[s] = acc; acc += hostCounts[s]; n_raw_to[s] = hostCounts[s]; }
-        if (acc != n) throw DyError(DY_EINVAL, "dy_raw_pack: seg_starts do not cover the reads of the last dy_map_bins");
-        HIP_CHECK(hipMemcpyAsync(cursors, hostCursor, (size_t)n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_raw_seg_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, (const u32 *)ids_dev, cursors,
+        u32 * segDev, * counts, * cursors;
+        segCursors(ctx, n_ranks, seg_starts, segDev, counts, cursors);
+        const u32 * orig = ctx->lastPaired ? ctx->shOrig.as<u32>() : nullptr;
+        hipLaunchKernelGGL(k_raw_seg_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, orig, counts);
+        if (segCountsToCursors(ctx, n_ranks, counts, cursors, n_raw_to) != n) throw DyError(DY_EINVAL, "dy_raw_pack: seg_starts do not cover the reads of the last dy_map_bins");
+        hipLaunchKernelGGL(k_raw_seg_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, orig, (const u32 *)ids_dev, cursors,
                            (RawMatch *)raw_out_dev);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
 }
 
-int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, const void * raw_dev, uint64_t n_raw, const uint32_t * bin_loads,
-                    dy_result ** out)
+int dy_pe_items_pack(dy_ctx * ctx, uint32_t n_ranks, const uint32_t * seg_starts, const void * ids_dev, void * items_out_dev, uint64_t * n_items_to)
 {
     return guarded([&] {
-        if (!ctx || !idx || !reads || !p || !bin_loads || !out || (n_raw && !raw_dev)) throw DyError(DY_EINVAL, "dy_finalize_raw: NULL argument");
+        if (!ctx || !seg_starts || !n_items_to) throw DyError(DY_EINVAL, "dy_pe_items_pack: NULL argument");
+        if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
+        if (!ctx->rawValid || !ctx->lastPaired) throw DyError(DY_EINVAL, "a paired dy_map_bins must run first");
+        for (u32 s = 0; s < n_ranks; ++s) if (seg_starts[s + 1] < seg_starts[s]) throw DyError(DY_EINVAL, "seg_starts must be non-decreasing");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 n = ctx->lastItems;
+        for (u32 s = 0; s < n_ranks; ++s) n_items_to[s] = 0;
+        if (!n) return;
+        if (!ids_dev || !items_out_dev) throw DyError(DY_EINVAL, "dy_pe_items_pack: NULL buffer");
+        u32 * segDev, * counts, * cursors;
+        segCursors(ctx, n_ranks, seg_starts, segDev, counts, cursors);
+        hipLaunchKernelGGL(k_pe_items_seg_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), n, segDev, n_ranks,
+                           ctx->shOrig.as<u32>(), counts);
+        (void)segCountsToCursors(ctx, n_ranks, counts, cursors, n_items_to);
+        hipLaunchKernelGGL(k_pe_items_seg_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(), n,
+                           segDev, n_ranks, ctx->shOrig.as<u32>(), (const u32 *)ids_dev, cursors, (PeItemRec *)items_out_dev);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, const void * raw_dev, uint64_t n_raw,
+                    const void * pe_items_dev, uint64_t n_pe_items, const uint32_t * bin_loads, dy_result ** out)
+{
+    return guarded([&] {
+        if (!ctx || !idx || !reads || !p || !bin_loads || !out || (n_raw && !raw_dev) || (n_pe_items && !pe_items_dev)) throw DyError(DY_EINVAL, "dy_finalize_raw: NULL argument");
         if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
-        if (p->paired) throw DyError(DY_EUNSUPPORTED, "paired-end mapping over sharded bins is not implemented");
         if (n_raw >= 0xFFFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+        const bool paired = p->paired != 0;
+        if (!paired && n_pe_items) throw DyError(DY_EINVAL, "dy_finalize_raw: paired-end item records given for a single-end batch");
+        if (paired && (reads->n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
+        if (n_pe_items >= 0xFFFFFFF0ull) throw DyError(DY_EINVAL, "dy_finalize_raw: too many item records");
         HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
-        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), nPool = (u32)n_raw;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), nPool = (u32)n_raw, W = (nBins + 63) / 64;
+        if (paired && (reads->maskW != W || reads->maskBins != nBins)) throw DyError(DY_EINVAL, "the reads carry no bin masks for this index (dy_ibf_query + dy_shard_plan first)");
         const u32 maxErr = readErrorsOf(reads->maxLen, p->error_rate);
-        std::unique_ptr<dy_result> res = makeResult(ctx, reads, maxErr);
+        const u32 maxMatchErr = maxMatchErrorsOf(reads, p, maxErr);
+        std::unique_ptr<dy_result> res = makeResult(ctx, reads, maxMatchErr);
         res->nPool = nPool;
         if (!nReads) { *out = res.release(); return; }
+        ctx->counters.reserve(COUNTER_BYTES);
+        ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
+        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, COUNTER_BYTES, st));
+        HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
+        HIP_CHECK(hipEventRecord(ctx->ev[5], st));
+        u32 nItems = 0;
+        if (paired)
+        {   // the home reads' own work list (their OR-ed masks) indexes the records of the owners: copyCigars, reference src/d_mapper.h:186-215
+            nItems = buildWorkList(ctx, reads, nBins);
+            ctx->peItems.reserve((size_t)nItems * sizeof(PeItem) + 64);
+            ctx->peHasRescue.reserve((size_t)nReads * 4 + 64);
+            HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
+            HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
+            if (n_pe_items)
+            {
+                PeView V = {};
+                V.items = ctx->peItems.as<PeItem>(); V.itemRead = ctx->itemRead.as<u32>(); V.itemBin = ctx->itemBin.as<u16>(); V.binStart = ctx->binStart.as<u32>();
+                V.nBins = nBins; V.nItems = nItems; V.readHasRescue = ctx->peHasRescue.as<u32>();
+                hipLaunchKernelGGL(k_pe_items_unpack, dim3((u32)((n_pe_items + 255) / 256)), dim3(256), 0, st, (const PeItemRec *)pe_items_dev, (u32)n_pe_items, V, nReads,
+                                   ctx->counters.as<u32>() + 7);
+            }
+        }
         // sortedBins() over the loads of the whole job (reference src/d_mapper.h:843-854), as k_items_bin_starts ranks them
         std::vector<u32> rank(nBins);
         for (u32 b = 0; b < nBins; ++b)
@@ -1476,19 +1631,14 @@ int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const 
         }
         ctx->binOrderRank.reserve((size_t)nBins * 4);
         HIP_CHECK(hipMemcpyAsync(ctx->binOrderRank.p, rank.data(), (size_t)nBins * 4, hipMemcpyHostToDevice, st));
-        ctx->counters.reserve(COUNTER_BYTES);
-        ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
-        HIP_CHECK(hipMemsetAsync(ctx->counters.p, 0, COUNTER_BYTES, st));
-        HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
-        HIP_CHECK(hipEventRecord(ctx->ev[5], st));
         if (nPool)
             hipLaunchKernelGGL(k_raw_read_counts, dim3((nPool + 255) / 256), dim3(256), 0, st, (const RawMatch *)raw_dev, nPool, nReads, ctx->readMatchCount.as<u32>(),
                                ctx->counters.as<u32>() + 7);
         u32 bad = 0;
         HIP_CHECK(hipMemcpyAsync(&bad, ctx->counters.as<u32>() + 7, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if (bad) throw DyError(DY_EINVAL, "dy_finalize_raw: a raw match names a read outside the batch");
-        runFinalize(ctx, idx, reads, p, res.get(), (const RawMatch *)raw_dev, nPool, 0, maxErr);
+        if (bad) throw DyError(DY_EINVAL, "dy_finalize_raw: a raw match or item record names a read / bin outside the batch's selection");
+        runFinalize(ctx, idx, reads, p, res.get(), (const RawMatch *)raw_dev, nPool, nItems, maxMatchErr, PE_HOME);
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
         res->readLens = reads->lens;
         u32 badGroup = 0;

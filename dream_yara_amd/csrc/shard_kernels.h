@@ -94,32 +94,141 @@ __device__ __forceinline__ u32 segmentOf(const u32 * __restrict__ segStarts, u32
     return s;
 }
 
-// raw matches per source rank (block-local histogram in LDS, one global atomic per block and rank)
-__global__ void k_raw_seg_count(const RawMatch * __restrict__ pool, u32 n, const u32 * __restrict__ segStarts, u32 nRanks, u32 * __restrict__ counts)
+// Paired batches on the owner: the reads arrive source rank by source rank, each segment = [first mates | second mates] of the pairs
+// that source selected for this owner; the child mapper wants [all first mates | all second mates] (reference src/d_mapper.h:394-443,
+// loadFilteredReads: reads, then mates), pairs in source order = the order of the concatenated job.  orig[j] = arrival index of read j.
+__global__ void k_pair_layout(const u32 * __restrict__ segStarts, u32 nRanks, u32 n, u32 * __restrict__ orig)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 P = n / 2, jj = j < P ? j : j - P;
+    u32 s = 0, before = 0;
+    for (;; ++s)
+    {
+        const u32 ps = (segStarts[s + 1] - segStarts[s]) / 2;
+        if (jj < before + ps || s + 1 == nRanks) break;
+        before += ps;
+    }
+    const u32 ps = (segStarts[s + 1] - segStarts[s]) / 2;
+    orig[j] = segStarts[s] + (j < P ? 0 : ps) + (jj - before);
+}
+
+// lens / masks of the permuted batch
+__global__ void k_permute_scalars(const u32 * __restrict__ orig, u32 n, u32 W, const u32 * __restrict__ lensIn, const u64 * __restrict__ masksIn,
+                                  u64 * __restrict__ lensOut /* n + 1, widened */, u64 * __restrict__ masksOut)
+{
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    if (j == n) { lensOut[j] = 0; return; }
+    const u32 o = orig[j];
+    lensOut[j] = lensIn[o];
+    for (u32 w = 0; w < W; ++w) masksOut[(size_t)j * W + w] = masksIn[(size_t)o * W + w];
+}
+
+// bases of the permuted batch: one wavefront per read
+__global__ void k_permute_bases(const u32 * __restrict__ orig, u32 n, const u64 * __restrict__ offsIn, const u8 * __restrict__ seqsIn,
+                                const u64 * __restrict__ offsOut, u8 * __restrict__ seqsOut)
+{
+    const u32 lane = threadIdx.x & 63;
+    const u32 gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nW = (gridDim.x * blockDim.x) >> 6;
+    for (u32 j = gw; j < n; j += nW)
+    {
+        const u64 src = offsIn[orig[j]], dst = offsOut[j];
+        const u32 len = (u32)(offsOut[j + 1] - dst);
+        for (u32 k = lane; k < len; k += 64) seqsOut[dst + k] = seqsIn[src + k];
+    }
+}
+
+// raw matches per source rank (block-local histogram in LDS, one global atomic per block and rank).
+// orig (may be NULL): arrival index of every read of the batch (paired batches are permuted on the owner).
+__global__ void k_raw_seg_count(const RawMatch * __restrict__ pool, u32 n, const u32 * __restrict__ segStarts, u32 nRanks, const u32 * __restrict__ orig,
+                                u32 * __restrict__ counts)
 {
     __shared__ u32 local[64];
     if (threadIdx.x < 64) local[threadIdx.x] = 0;
     __syncthreads();
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) atomicAdd(&local[segmentOf(segStarts, nRanks, pool[t].read)], 1u);
+    if (t < n) { const u32 r = pool[t].read; atomicAdd(&local[segmentOf(segStarts, nRanks, orig ? orig[r] : r)], 1u); }
     __syncthreads();
     if (threadIdx.x < nRanks && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
 }
 
 // cursors[s] starts at the first output slot of rank s; read ids are rewritten to the ids of the home rank
-__global__ void k_raw_seg_scatter(const RawMatch * __restrict__ pool, u32 n, const u32 * __restrict__ segStarts, u32 nRanks, const u32 * __restrict__ ids,
-                                  u32 * __restrict__ cursors, RawMatch * __restrict__ out)
+__global__ void k_raw_seg_scatter(const RawMatch * __restrict__ pool, u32 n, const u32 * __restrict__ segStarts, u32 nRanks, const u32 * __restrict__ orig,
+                                  const u32 * __restrict__ ids, u32 * __restrict__ cursors, RawMatch * __restrict__ out)
 {
     __shared__ u32 local[64], base[64];
     if (threadIdx.x < 64) local[threadIdx.x] = 0;
     __syncthreads();
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    RawMatch m; u32 s = 0, my = 0;
-    if (t < n) { m = pool[t]; s = segmentOf(segStarts, nRanks, m.read); my = atomicAdd(&local[s], 1u); }
+    RawMatch m; u32 s = 0, my = 0, arrival = 0;
+    if (t < n) { m = pool[t]; arrival = orig ? orig[m.read] : m.read; s = segmentOf(segStarts, nRanks, arrival); my = atomicAdd(&local[s], 1u); }
     __syncthreads();
     if (threadIdx.x < nRanks) base[threadIdx.x] = local[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], local[threadIdx.x]) : 0;
     __syncthreads();
-    if (t < n) { m.read = ids[m.read]; out[base[s] + my] = m; }
+    if (t < n) { m.read = ids[arrival]; out[base[s] + my] = m; }
+}
+
+// ---- paired-end over sharded bins: what the home rank needs of a child mapper besides its raw matches — the primary the pairing
+// chose, `paired` + probability (reference src/d_mapper.h:186-215 copyCigars ships exactly these) and a rescued mate.  40 bytes.
+struct PeItemRec { u32 read; u16 bin; u8 paired; u8 rescued; u32 primary; u32 reserved; double prob; RawMatch mate; };
+static_assert(sizeof(PeItemRec) == 40, "DY_PE_ITEM_BYTES");
+
+__device__ __forceinline__ bool peItemWorthSending(const PeItem & it) { return it.nU2 || it.rescued || it.paired; }
+
+__global__ void k_pe_items_seg_count(const PeItem * __restrict__ items, const u32 * __restrict__ itemRead, u32 nItems, const u32 * __restrict__ segStarts, u32 nRanks,
+                                     const u32 * __restrict__ orig, u32 * __restrict__ counts)
+{
+    __shared__ u32 local[64];
+    if (threadIdx.x < 64) local[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nItems && peItemWorthSending(items[t])) atomicAdd(&local[segmentOf(segStarts, nRanks, orig[itemRead[t]])], 1u);
+    __syncthreads();
+    if (threadIdx.x < nRanks && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], local[threadIdx.x]);
+}
+
+__global__ void k_pe_items_seg_scatter(const PeItem * __restrict__ items, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin, u32 nItems,
+                                       const u32 * __restrict__ segStarts, u32 nRanks, const u32 * __restrict__ orig, const u32 * __restrict__ ids,
+                                       u32 * __restrict__ cursors, PeItemRec * __restrict__ out)
+{
+    __shared__ u32 local[64], base[64];
+    if (threadIdx.x < 64) local[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    bool send = false; u32 s = 0, my = 0, arrival = 0;
+    PeItem it;
+    if (t < nItems)
+    {
+        it = items[t];
+        send = peItemWorthSending(it);
+        if (send) { arrival = orig[itemRead[t]]; s = segmentOf(segStarts, nRanks, arrival); my = atomicAdd(&local[s], 1u); }
+    }
+    __syncthreads();
+    if (threadIdx.x < nRanks) base[threadIdx.x] = local[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], local[threadIdx.x]) : 0;
+    __syncthreads();
+    if (send)
+    {
+        PeItemRec r;
+        r.read = ids[arrival]; r.bin = itemBin[t]; r.paired = it.paired ? 1 : 0; r.rescued = it.rescued ? 1 : 0; r.primary = it.primary; r.reserved = 0;
+        r.prob = it.prob; r.mate = it.mate;
+        if (it.rescued) r.mate.read = r.read; else { r.mate.read = 0; r.mate.begin = 0; r.mate.len = 0; r.mate.errors = 0; r.mate.strand = 0; r.mate.bin = 0; r.mate.contig = 0; }
+        out[base[s] + my] = r;
+    }
+}
+
+// home rank: the records land in the items of the home reads' own work list
+__global__ void k_pe_items_unpack(const PeItemRec * __restrict__ recs, u32 n, PeView V, u32 nReads, u32 * __restrict__ bad)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const PeItemRec r = recs[t];
+    if (r.read >= nReads || r.bin >= V.nBins) { atomicExch(bad, 1u); return; }
+    const u32 item = peFindItem(V, r.read, r.bin);
+    if (item >= V.binStart[r.bin + 1] || V.itemRead[item] != r.read) { atomicExch(bad, 1u); return; }    // the read did not select that bin
+    PeItem & it = V.items[item];
+    it.primary = r.primary; it.paired = r.paired; it.rescued = r.rescued; it.prob = r.prob; it.mate = r.mate;
+    if (r.rescued) V.readHasRescue[r.read] = 1;
 }
 
 __global__ void k_raw_read_counts(const RawMatch * __restrict__ raw, u32 n, u32 nReads, u32 * __restrict__ readMatchCount, u32 * __restrict__ bad)

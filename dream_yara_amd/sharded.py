@@ -6,7 +6,8 @@ copyMatches / finalizeMainMapper (reference src/d_mapper.h:127-155, 828-838, 876
 
   C0  sum(read lengths), count        all-reduce   -> the batch's one IBF threshold (src/d_mapper.h:314)
   C1  reads -> owners of selected bins all-to-all(v) ids, lengths, masks, bases
-  C2  raw matches -> home ranks        all-to-all(v) 16 B records
+  C2  raw matches -> home ranks        all-to-all(v) 16 B records (+ 40 B pairing records per (read,bin) for paired jobs: the child's
+                                                     primary, `paired`, pair probability, rescued mate — what copyCigars ships, :186-215)
   C3  items per bin                    all-reduce   -> sortedBins() order for the CIGAR provenance rule (:843-854)
 """
 import numpy as np
@@ -69,8 +70,9 @@ class ShardedMapper:
         """reads: this rank's dy.Reads.  Returns a dy.Result for them, equal to the single-GPU result on the whole job."""
         ctx, dev, W = self.ctx, self.device, self.W
         u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        paired = bool(params.paired)
         self.ibf.query(reads, threshold, want_masks=False)                          # K1
-        n_to, b_to = dy.shard_plan(ctx, reads, self.owner_masks)                    # C1 pack
+        n_to, b_to = dy.shard_plan(ctx, reads, self.owner_masks, paired)            # C1 pack (paired: mates vote and travel together)
         n_tot, b_tot = int(n_to.sum()), int(b_to.sum())
         ids, lens, masks, seqs = u8(n_tot * 4), u8(n_tot * 4), u8(n_tot * W * 8), u8(b_tot)
         torch.cuda.synchronize()
@@ -81,20 +83,29 @@ class ShardedMapper:
         r_seqs, _ = exchange_bytes(self.dist, seqs, b_to.astype(np.int64), dev)
         torch.cuda.synchronize()
         n_recv = r_ids.numel() // 4
-        sub = dy.Reads.from_device(ctx, r_seqs.data_ptr(), r_lens.data_ptr(), r_masks.data_ptr(), n_recv, r_seqs.numel(), self.n_bins)
-        loads, n_raw = dy.map_bins(ctx, self.index, sub, params)                     # K2 + K3 on the owner
         seg = np.zeros(self.world + 1, np.uint32); seg[1:] = np.cumsum([x // 4 for x in rs])
+        sub = dy.Reads.from_device(ctx, r_seqs.data_ptr(), r_lens.data_ptr(), r_masks.data_ptr(), n_recv, r_seqs.numel(), self.n_bins,
+                                   paired_seg_starts=seg if paired else None)
+        loads, n_raw = dy.map_bins(ctx, self.index, sub, params)                     # K2 + K3 (+ pairing, rescue) on the owner
         raw = u8(n_raw * dy.RAW_MATCH_BYTES)
         torch.cuda.synchronize()
         raw_to = dy.raw_pack(ctx, seg, r_ids.data_ptr(), raw.data_ptr())             # C2 pack
+        r_items, n_items_in = None, 0
+        if paired:
+            items = u8(int(loads.sum()) * dy.PE_ITEM_BYTES)
+            items_to = dy.pe_items_pack(ctx, seg, r_ids.data_ptr(), items.data_ptr())
+            n_sent = int(items_to.sum())
+            r_items, _ = exchange_bytes(self.dist, items[: n_sent * dy.PE_ITEM_BYTES], items_to.astype(np.int64) * dy.PE_ITEM_BYTES, dev)
+            n_items_in = r_items.numel() // dy.PE_ITEM_BYTES
         sub.close()
         r_raw, _ = exchange_bytes(self.dist, raw, raw_to.astype(np.int64) * dy.RAW_MATCH_BYTES, dev)
         g_loads = all_reduce_sum(self.dist, loads, dev)                              # C3
         torch.cuda.synchronize()
         self.last = {"sent_reads": n_tot, "recv_reads": n_recv, "raw_out": n_raw, "raw_in": r_raw.numel() // dy.RAW_MATCH_BYTES,
                      "items": int(g_loads.sum())}
+        self.last["pe_items_in"] = n_items_in
         res = dy.finalize_raw(ctx, self.index, reads, params, r_raw.data_ptr(), r_raw.numel() // dy.RAW_MATCH_BYTES,
-                              g_loads.astype(np.uint32))                             # K4 on the home rank
+                              g_loads.astype(np.uint32), r_items.data_ptr() if n_items_in else None, n_items_in)    # K4 on the home rank
         return res
 
     def close(self):

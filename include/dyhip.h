@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DY_ABI_VERSION 1
+#define DY_ABI_VERSION 2
 
 enum {
     DY_OK = 0,
@@ -188,23 +188,26 @@ int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
 
 /* ---- bins sharded over ranks (one process per GPU) -------------------------------------------------------
  * The reference's unit of distribution is the bin (src/d_mapper.h:876-884: one child Mapper per bin; copyMatches
- * :127-155 and finalizeMainMapper :828-838 merge per read).  With G ranks every rank holds the filter, the contig
- * text of ALL bins (the home rank of a read aligns its primary) and the FM structures of the bins it owns.
- * A batch step on rank r, with the three exchanges done by the caller (RCCL / MPI all-to-all on caller-owned
- * DEVICE buffers; the library never communicates):
+ * :127-155, copyCigars :186-215 and finalizeMainMapper :828-838 merge per read).  With G ranks every rank holds the filter,
+ * the contig text of ALL bins (the home rank of a read aligns its primary) and the FM structures of the bins it owns.
+ * A batch step on rank r, with the exchanges done by the caller (RCCL / MPI all-to-all on caller-owned DEVICE buffers;
+ * the library never communicates):
  *   dy_ibf_query(home reads)                              K1 on the rank's own reads
  *   dy_shard_plan / dy_shard_pack                         [C1] reads selected for each owner rank  -> all-to-all
- *   dy_reads_from_device + dy_map_bins                    K2+K3 on the owner, for its bins only
- *   dy_raw_pack                                           [C2] raw matches back to each read's home -> all-to-all
- *   dy_finalize_raw(home reads, all raw matches, global bin loads)   K4 = aggregate + rankMatches2 on the home rank
+ *   dy_reads_from_device(_paired) + dy_map_bins           K2+K3 on the owner, for its bins only (paired: + the child mapper's
+ *                                                         pairing, library statistics and mate rescue, which are bin-local)
+ *   dy_raw_pack (+ dy_pe_items_pack)                      [C2] raw matches (+ per-(read,bin) pairing records) -> the read's home
+ *   dy_finalize_raw(home reads, raw matches, records, global bin loads)   K4 = aggregate + rankMatches2 on the home rank
  * `bin_loads` (items per bin, summed over ranks by the caller) orders the bins like sortedBins() (:843-854) does.
- * Results equal dy_map_reads on the concatenation of all ranks' reads.  Single-end only (DY_EUNSUPPORTED otherwise). */
+ * Results equal dy_map_reads on the concatenation of all ranks' reads; for a paired job the concatenation is
+ * [first mates of rank 0, first mates of rank 1, ... | second mates of rank 0, ...] (mates stay together: src/d_mapper.h:350-358). */
 
 /* Like dy_index_load, but FM structures only for bins with owned[b] != 0 (contigs and names for all). */
 int  dy_index_load_sharded(dy_ctx *ctx, const char *dir, uint32_t n_bins, const uint8_t *owned, dy_index **out);
-/* owner_masks: n_ranks x W words (host), rank d's bit set of owned bins.  Out (host, n_ranks entries each): how many
- * of `reads` have a selected bin on rank d, and their total bases.  loadFilteredReads — reference src/d_mapper.h:394-443. */
-int  dy_shard_plan(dy_ctx *ctx, const dy_reads *reads, uint32_t n_ranks, const uint64_t *owner_masks,
+/* owner_masks: n_ranks x W words (host), rank d's bit set of owned bins.  paired != 0: `reads` holds first mates then second mates
+ * and the masks of the two mates are OR-ed first, so both travel wherever either is selected.  Out (host, n_ranks entries each):
+ * how many of `reads` have a selected bin on rank d, and their total bases.  loadFilteredReads — reference src/d_mapper.h:394-443. */
+int  dy_shard_plan(dy_ctx *ctx, const dy_reads *reads, uint32_t n_ranks, const uint64_t *owner_masks, uint32_t paired,
                    uint32_t *n_reads_to, uint64_t *n_bases_to);
 /* Fills the caller's DEVICE buffers, destination-major, in read order inside a destination: ids (u32 read id on this
  * rank), lens (u32), masks (W words per read, restricted to the destination's bins), seqs (forward Dna5 codes). */
@@ -212,16 +215,28 @@ int  dy_shard_pack(dy_ctx *ctx, const dy_reads *reads, void *ids_dev, void *lens
 /* A reads batch from DEVICE buffers in the layout dy_shard_pack writes (n reads, n_bases bases, W mask words per read). */
 int  dy_reads_from_device(dy_ctx *ctx, const void *seqs_dev, const void *lens_dev, const void *masks_dev,
                           uint32_t n_reads, uint64_t n_bases, uint32_t n_bins, dy_reads **out);
-/* K2 + K3 over the (read,bin) items of the masks.  bin_loads (host, n_bins) receives the items per bin; the raw
- * matches stay in the context until dy_raw_pack. */
+/* Same for a paired job: reads [seg_starts[s], seg_starts[s+1]) arrived from rank s (an even number: that rank's selected
+ * first mates, then their second mates); the batch is re-ordered to [all first mates | all second mates], pairs in source
+ * order, which is what the child mapper sees in the reference (src/d_mapper.h:394-443). */
+int  dy_reads_from_device_paired(dy_ctx *ctx, const void *seqs_dev, const void *lens_dev, const void *masks_dev,
+                                 uint32_t n_reads, uint64_t n_bases, uint32_t n_bins, uint32_t n_ranks, const uint32_t *seg_starts, dy_reads **out);
+/* K2 + K3 over the (read,bin) items of the masks; with p->paired also the bin-local pairing stages of the child mapper
+ * (reference src/mapper.h:927-1172).  bin_loads (host, n_bins) receives the items per bin; the raw matches (and pairing
+ * records) stay in the context until dy_raw_pack / dy_pe_items_pack. */
 int  dy_map_bins(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, uint32_t *bin_loads, uint64_t *n_raw);
-/* Rewrites the read id of every raw match of the last dy_map_bins through ids_dev and orders them by source rank:
- * reads [seg_starts[s], seg_starts[s+1]) came from rank s.  raw_out_dev: n_raw x 16 B (DEVICE); n_raw_to: host. */
+/* Rewrites the read id of every raw match of the last dy_map_bins through ids_dev (indexed by arrival order) and orders them
+ * by source rank: reads [seg_starts[s], seg_starts[s+1]) came from rank s.  raw_out_dev: n_raw x 16 B (DEVICE); n_raw_to: host. */
 int  dy_raw_pack(dy_ctx *ctx, uint32_t n_ranks, const uint32_t *seg_starts, const void *ids_dev, void *raw_out_dev, uint64_t *n_raw_to);
-/* K4 on the home rank over raw matches gathered from all owners (DEVICE, 16 B each). */
+/* Paired jobs: one DY_PE_ITEM_BYTES record per (read,bin) item of the last dy_map_bins that carries information — the child's
+ * primary as chosen by the pairing, `paired`, the pair probability, a rescued mate (what copyCigars ships, reference
+ * src/d_mapper.h:186-215) — ordered by source rank like dy_raw_pack.  items_out_dev must hold sum(bin_loads) records. */
+int  dy_pe_items_pack(dy_ctx *ctx, uint32_t n_ranks, const uint32_t *seg_starts, const void *ids_dev, void *items_out_dev, uint64_t *n_items_to);
+/* K4 on the home rank over raw matches gathered from all owners (DEVICE, 16 B each); paired jobs also pass the gathered
+ * pairing records (pe_items_dev, n_pe_items; NULL / 0 for single-end). */
 int  dy_finalize_raw(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, const void *raw_dev, uint64_t n_raw,
-                     const uint32_t *bin_loads, dy_result **out);
+                     const void *pe_items_dev, uint64_t n_pe_items, const uint32_t *bin_loads, dy_result **out);
 #define DY_RAW_MATCH_BYTES 16
+#define DY_PE_ITEM_BYTES 40
 
 #ifdef __cplusplus
 }

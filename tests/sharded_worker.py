@@ -19,23 +19,35 @@ from dream_yara_amd.dist import Group
 
 def main():
     work, n_bins, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    paired = len(sys.argv) > 5 and sys.argv[5] == "paired"
     g = Group("gloo")
     torch.cuda.set_device(0)
     data = np.load(os.path.join(work, "reads.npz"))
     codes, offs = data["codes"], data["offs"]
     n = offs.size - 1
-    cut = [0, n * 2 // 5, n] if g.world == 2 else [round(i * n / g.world) for i in range(g.world + 1)]     # uneven shards
+    units = n // 2 if paired else n                      # what is split across ranks: pairs or reads
+    cut = [0, units * 2 // 5, units] if g.world == 2 else [round(i * units / g.world) for i in range(g.world + 1)]     # uneven shards
     lo, hi = cut[g.rank], cut[g.rank + 1]
-    my_codes = codes[int(offs[lo]):int(offs[hi])]
-    my_offs = (offs[lo:hi + 1] - offs[lo]).astype(np.uint64)
+
+    def take(a, b):
+        return codes[int(offs[a]):int(offs[b])], (offs[a:b + 1] - offs[a]).astype(np.uint64)
+    if paired:
+        # the whole job is [first mates of rank 0, of rank 1, ... | second mates of rank 0, ...]; this rank's batch: its first mates, then its second mates
+        P = units
+        c1, o1 = take(lo, hi); c2, o2 = take(P + lo, P + hi)
+        my_codes = np.concatenate([c1, c2]); my_offs = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+        mine_idx = np.concatenate([np.arange(lo, hi), np.arange(P + lo, P + hi)])
+    else:
+        my_codes, my_offs = take(lo, hi)
+        mine_idx = np.arange(lo, hi)
     er, sr = np.float32(0.03), np.float32(float(sys.argv[4]))
     ctx = dy.Context(0)
     ibf = dy.Ibf.load(ctx, os.path.join(work, "f.filter"))
-    params = dy.default_params(error_rate=er, strata_rate=sr)
+    params = dy.default_params(error_rate=er, strata_rate=sr, paired=1 if paired else 0)
 
     sm = sharded.ShardedMapper(ctx, dist, g.rank, g.world, os.path.join(work, "idx"), n_bins, ibf, "cuda")
     reads = dy.Reads(ctx, my_codes, my_offs)
-    thr = sm.threshold(er, k, int(my_offs[-1]), hi - lo)
+    thr = sm.threshold(er, k, int(my_offs[-1]), my_offs.size - 1)
     res = sm.map(reads, params, thr)
     res.fetch()
     got = (res.reads(), res.matches(), res.cigars())
@@ -54,11 +66,11 @@ def main():
     ref.close(); allr.close(); full.close(); ibf.close()
 
     bad = []
-    mine = rr[lo:hi]
-    for f in ("primary", "mapped", "best_count", "sub_count", "mapq", "cigar_len"):
+    mine = rr[mine_idx]
+    for f in ("primary", "mapped", "best_count", "sub_count", "mapq", "cigar_len", "paired", "pair_prob"):
         if not np.array_equal(got[0][f], mine[f]):
             bad.append(f)
-    for i in range(hi - lo):
+    for i in range(mine_idx.size):
         a, b = got[0][i], mine[i]
         na, nb = int(a["best_count"] + a["sub_count"]), int(b["best_count"] + b["sub_count"])
         if na != nb or not np.array_equal(got[1][int(a["set_begin"]):int(a["set_begin"]) + na], rm[int(b["set_begin"]):int(b["set_begin"]) + nb]):
@@ -68,7 +80,8 @@ def main():
             bad.append("cigar%d" % i); break
     if info["items"] != items:
         bad.append("items %d != %d" % (info["items"], items))
-    info.update(rank=g.rank, bad=bad, mapped=int(got[0]["mapped"].sum()), n=hi - lo)
+    info.update(rank=g.rank, bad=bad, mapped=int(got[0]["mapped"].sum()), n=int(mine_idx.size), paired_reads=int(got[0]["paired"].sum()),
+                gapped=int((got[0]["cigar_len"] > 1).sum()))
     open(os.path.join(work, "out%d.json" % g.rank), "w").write(json.dumps(info))
     g.barrier(); g.close(); ctx.close()
     sys.exit(1 if bad else 0)

@@ -1018,11 +1018,22 @@ def test_cli_errors_exit_1_with_the_tool_name(product_build, small_filter, tmp_p
 
 
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
+def _run_sharded_workers(tmp_path, n_bins, k, strata, port, extra=()):
+    import sys, json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(os.path.dirname(__file__), "sharded_worker.py"), str(tmp_path), str(n_bins), str(k),
+                          str(strata)] + list(extra), env=env, timeout=600)
+    outs = [json.load(open(tmp_path / ("out%d.json" % r))) for r in range(2)]
+    assert rc == 0, outs
+    assert all(o["bad"] == [] for o in outs), outs
+    return outs
+
+
 @pytest.mark.parametrize("strata,n_bins", [(0.0, 6), (0.02, 6), (0.0, 70)])
 def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata, n_bins):
     """two ranks (both on cuda:0, exchanges over gloo) each hold the FM structures of half the bins; the
     merged per-read results equal the single-GPU run on the concatenated batch (which the other tests tie to the oracle)."""
-    import sys, json
     rng = np.random.default_rng(99)
     k = 16
     genomes, fam = _repeat_genomes(rng, n_bins, 60000 if n_bins < 10 else 8000)      # 70 bins: two mask words per read
@@ -1033,17 +1044,34 @@ def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, str
     ob.build_filter(str(tmp_path / "f.filter"), n_bins, 3, k, 1 << 24, np.concatenate(genomes), goffs)
     codes, offs = _sample_reads(rng, genomes, fam, 2998, 100, 3)
     np.savez(str(tmp_path / "reads.npz"), codes=codes, offs=offs)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29617", os.path.join(os.path.dirname(__file__), "sharded_worker.py"), str(tmp_path), str(n_bins), str(k),
-                          str(strata)], env=env, timeout=600)
-    outs = [json.load(open(tmp_path / ("out%d.json" % r))) for r in range(2)]
-    assert rc == 0, outs
-    assert all(o["bad"] == [] for o in outs)
+    outs = _run_sharded_workers(tmp_path, n_bins, k, strata, 29617)
     assert sum(o["n"] for o in outs) == 3000 and sum(o["mapped"] for o in outs) > 2000
     assert all(o["recv_reads"] > 0 and o["raw_in"] > 0 for o in outs)                 # both exchanges carried data
     assert sum(o["sent_reads"] for o in outs) == sum(o["recv_reads"] for o in outs)
     assert sum(o["raw_out"] for o in outs) == sum(o["raw_in"] for o in outs)
+
+
+@pytest.mark.parametrize("strata,n_bins", [(0.0, 5), (0.02, 70)])
+def test_bin_sharded_paired_end_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata, n_bins):
+    """BASELINE configs[3]'s partitioning: paired-end over bins sharded across ranks.  Mates travel together to the owners of the bins
+    either selects; the owner runs the child mapper's pairing, library statistics and mate rescue for its bins (reference
+    src/mapper.h:927-1172) and ships raw matches + per-(read,bin) pairing records home, where the per-read merge runs
+    (copyMatches / copyCigars, src/d_mapper.h:127-215).  Every field of every read equals the single-GPU paired run on the whole job."""
+    rng = np.random.default_rng(4100 + n_bins)
+    k = 16
+    genomes = [rng.integers(0, 4, 50000 if n_bins < 10 else 9000, dtype=np.uint8) for _ in range(n_bins)]
+    genomes[1][3000:3400] = genomes[1][7000:7400]                                  # a repeat: several co-optimal pairs
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    ob.build_filter(str(tmp_path / "f.filter"), n_bins, 3, k, 1 << 24, np.concatenate(genomes), goffs)
+    codes, offs = _make_pairs(rng, genomes, 1500, 100)                             # long-indel and hopeless mates: work for the rescue
+    np.savez(str(tmp_path / "reads.npz"), codes=codes, offs=offs)
+    outs = _run_sharded_workers(tmp_path, n_bins, k, strata, 29619, ["paired"])
+    assert sum(o["n"] for o in outs) == 3000 and sum(o["mapped"] for o in outs) > 2500
+    assert sum(o["paired_reads"] for o in outs) > 2000 and sum(o["gapped"] for o in outs) > 50
+    assert all(o["recv_reads"] > 0 and o["raw_in"] > 0 and o["pe_items_in"] > 0 for o in outs)
 
 
 # ---------------------------------------------------------------------------------------------- larger sizes: properties
