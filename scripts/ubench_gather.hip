@@ -1,54 +1,83 @@
-// Micro-benchmark: ceiling for random 8-byte gathers over a 1 GiB table on MI355X (what K1 is bound by).
-// hipcc --offload-arch=gfx950 -O3 -o ubench_gather scripts/ubench_gather.hip && ./ubench_gather
+// Micro-benchmark: the chip's ceiling for random gathers of 8 .. 128 bytes over tables of 64 MiB .. 64 GiB on MI355X — what K1 (the
+// IBF sweep) is bound by.  A request of `width` bytes is served by G adjacent lanes, each loading V x 8 bytes of one aligned
+// group (the production kernels use V = 1: one 64-bit word per lane), every request at an independent pseudo-random position.
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/ubench_gather scripts/ubench_gather.hip && scripts/ubench_gather [max_gib] > profiles/<round>_gather_sweep.jsonl
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#include <vector>
+#include <cstdlib>
 typedef uint64_t u64;
-template <int ILP, bool NT>
-__global__ void gather(const u64 * __restrict__ t, u64 mask, u64 n, u64 * out)
+typedef uint32_t u32;
+
+template <int G, int V, int ILP>
+__global__ __launch_bounds__(256) void gather(const u64 * __restrict__ t, u64 groupMask, u64 nReq, u64 * out)
 {
-    u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 req0 = tid / G, nLanesReq = ((u64)gridDim.x * blockDim.x) / G;
+    const u32 sub = (u32)(tid % G);
     u64 acc = 0;
-    for (u64 i = tid; i < n; i += (u64)gridDim.x * blockDim.x * ILP)
+    for (u64 i = req0; i < nReq; i += nLanesReq * ILP)
     {
-        u64 v[ILP];
+        u64 v[ILP][V];
 #pragma unroll
         for (int k = 0; k < ILP; ++k)
         {
-            u64 h = (i + (u64)k * gridDim.x * blockDim.x) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-            const u64 * p = t + (h & mask);
-            v[k] = NT ? __builtin_nontemporal_load(p) : *p;
+            u64 h = (i + (u64)k * nLanesReq) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            const u64 * p = t + (h & groupMask) * (u64)(G * V) + (u64)sub * V;
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[k][e] = p[e];
         }
 #pragma unroll
-        for (int k = 0; k < ILP; ++k) acc &= v[k] | 1;
-        acc += v[0];
+        for (int k = 0; k < ILP; ++k)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc += v[k][e] | 1;
     }
     if (acc == 0x1234567) out[0] = acc;
 }
-template <int ILP, bool NT> void run(const u64 * t, u64 words, u64 * out, int blocks, int threads)
+
+template <int G, int V, int ILP> void run(const u64 * t, u64 tableBytes, u64 * out)
 {
-    const u64 n = 512ull << 20;   // gathers
+    const u64 nReq = 256ull << 20;
+    const u64 groups = tableBytes / (8ull * G * V);            // power of two
+    const int blocks = 256 * 8, threads = 256;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((gather<ILP, NT>), dim3(blocks), dim3(threads), 0, 0, t, words - 1, n, out);
+    hipLaunchKernelGGL((gather<G, V, ILP>), dim3(blocks), dim3(threads), 0, 0, t, groups - 1, nReq, out);
     hipEventRecord(a);
-    hipLaunchKernelGGL((gather<ILP, NT>), dim3(blocks), dim3(threads), 0, 0, t, words - 1, n, out);
+    hipLaunchKernelGGL((gather<G, V, ILP>), dim3(blocks), dim3(threads), 0, 0, t, groups - 1, nReq, out);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    printf("ILP %d nt %d blocks %d x %d: %.2f ms, %.1f G gathers/s, %.2f TB/s of 64-B lines\n", ILP, (int)NT, blocks, threads, ms, n / ms / 1e6, n * 64.0 / ms / 1e9);
+    const int width = 8 * G * V;
+    printf("{\"table_mib\": %llu, \"width_bytes\": %d, \"lanes_per_request\": %d, \"bytes_per_lane\": %d, \"ilp\": %d, \"ms\": %.3f, \"G_requests_per_s\": %.2f, "
+           "\"TB_per_s_requested\": %.3f, \"TB_per_s_of_64B_lines\": %.3f}\n",
+           (unsigned long long)(tableBytes >> 20), width, G, 8 * V, ILP, ms, nReq / ms / 1e6, nReq * (double)width / ms / 1e9,
+           nReq * (double)(width < 64 ? 64 : width) / ms / 1e9);
+    fflush(stdout);
+    hipEventDestroy(a); hipEventDestroy(b);
 }
-int main()
+
+int main(int argc, char ** argv)
 {
-    const u64 words = 1ull << 27;  // 1 GiB
+    const u64 maxGib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 64;
     u64 * t; u64 * out;
-    hipMalloc(&t, words * 8); hipMalloc(&out, 8);
-    hipMemset(t, 0x5a, words * 8);
-    run<1, false>(t, words, out, 256 * 8, 256);
-    run<3, false>(t, words, out, 256 * 8, 256);
-    run<3, false>(t, words, out, 256 * 16, 512);
-    run<8, false>(t, words, out, 256 * 8, 256);
-    run<8, true>(t, words, out, 256 * 8, 256);
-    run<16, false>(t, words, out, 256 * 8, 256);
-    run<3, true>(t, words, out, 256 * 16, 512);
+    if (hipMalloc(&t, maxGib << 30) != hipSuccess) { fprintf(stderr, "cannot allocate %llu GiB\n", (unsigned long long)maxGib); return 1; }
+    hipMalloc(&out, 8);
+    hipMemset(t, 0x5a, maxGib << 30);
+    hipDeviceSynchronize();
+    for (u64 mib = 64; mib <= (maxGib << 10); mib *= 4)
+    {
+        const u64 bytes = mib << 20;
+        run<1, 1, 4>(t, bytes, out);     //   8 B: one lane, one word (W = 1: 64 bins)
+        run<1, 2, 4>(t, bytes, out);     //  16 B: one lane, dwordx4
+        run<2, 1, 4>(t, bytes, out);     //  16 B: two lanes
+        run<4, 1, 4>(t, bytes, out);     //  32 B: four lanes (W = 4: 256 bins)
+        run<2, 2, 4>(t, bytes, out);     //  32 B: two lanes x 16 B
+        run<8, 1, 4>(t, bytes, out);     //  64 B
+        run<4, 2, 4>(t, bytes, out);     //  64 B: four lanes x 16 B
+        run<16, 1, 4>(t, bytes, out);    // 128 B: sixteen lanes (W = 16: 1024 bins)
+        run<8, 2, 4>(t, bytes, out);     // 128 B: eight lanes x 16 B
+        run<16, 1, 8>(t, bytes, out);    // 128 B, more requests in flight
+        run<4, 1, 8>(t, bytes, out);
+        run<1, 1, 8>(t, bytes, out);
+    }
     return 0;
 }
