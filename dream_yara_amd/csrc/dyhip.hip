@@ -123,6 +123,8 @@ struct Tuning
     u64 ibfFullTail = 0;        // 1 = k_ibf_query<7> instead of k_ibf_query_two
     u64 ibfLdsKb = 12;          // LDS per wave of k_ibf_query_wide
     u64 ibfDense = 0;           // 1 = no sparse verification in k_ibf_query_wide
+    u64 ibfKernel = 0;          // sweep for W > 1 and reads of at most 255 k-mers: 0 = by expected false candidates, 1 = k_ibf_query_lazy, 2 = k_ibf_query_eager2, 3 = k_ibf_query_wide
+    u64 ibfSlack = 0;           // first check of the sweeps = nK - threshold + slack k-mers (0 = derived from the filter's fill)
     u64 poolCap = 0;            // initial capacity of the raw-match pool (0 = 2 x items); it grows on overflow either way
 };
 
@@ -194,7 +196,55 @@ struct dy_ibf
     IbfGeom g = {};
     DevBuf words;
     size_t nWords = 0;
+    double fill = 0.0; bool fillKnown = false;     // fraction of set bits (sampled), refreshed after the filter changed
 };
+
+// Fraction of set bits of the table, from an evenly spread sample of 2^18 words (dy_ibf_add / clear invalidate it).
+static double ibfFill(dy_ibf * f)
+{
+    if (f->fillKnown) return f->fill;
+    dy_ctx * ctx = f->ctx;
+    const u64 nTable = f->g.nHashPos * f->g.W;
+    const u32 nSamples = (u32)std::min<u64>(nTable, 1u << 18);
+    ctx->shTotals.reserve(64);
+    HIP_CHECK(hipMemsetAsync(ctx->shTotals.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_ibf_fill_sample, dim3((nSamples + 255) / 256), dim3(256), 0, ctx->stream, f->words.as<u64>(), nTable, nSamples, ctx->shTotals.as<unsigned long long>());
+    unsigned long long total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, ctx->shTotals.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    f->fill = (double)total / (64.0 * nSamples);
+    f->fillKnown = true;
+    return f->fill;
+}
+
+// The sweeps first look at nK - threshold + slack k-mers (a bin without hits is out of reach after nK - threshold + 1): slack = the
+// number of false hits that less than 1 in 20 reads sees any of the bins collect among that many k-mers (Poisson tail on the fill).
+// Only the speed depends on it, never a result.
+static u32 ibfSlack(dy_ibf * f, u32 nKmers, u32 threshold)
+{
+    if (f->ctx->tune.ibfSlack) return (u32)f->ctx->tune.ibfSlack;
+    if (threshold == 0 || threshold > nKmers) return 1;
+    const double lambda = ibfFill(f) * (double)(nKmers - threshold + 1);
+    double term = std::exp(-lambda), cdf = 0.0;        // P(X = 0)
+    for (u32 s = 1; s < threshold; ++s)
+    {
+        cdf += term;                                   // P(X < s)
+        if ((double)f->g.nBins * (1.0 - cdf) < 0.05) return s;
+        term *= lambda / (double)s;
+    }
+    return threshold;
+}
+
+// Bins per strand expected to pass the threshold on hash function 0 alone although the read is not theirs (Poisson tail on the fill):
+// well below one -> k_ibf_query_lazy verifies just the read's own bin; dozens -> k_ibf_query_eager2 (two hash functions up front).
+static double ibfExpectedFalseCandidates(dy_ibf * f, u32 nKmers, u32 threshold)
+{
+    if (threshold == 0 || threshold > nKmers) return 0.0;
+    const double lambda = ibfFill(f) * (double)nKmers;
+    double term = std::exp(-lambda), cdf = 0.0;
+    for (u32 s = 0; s < threshold; ++s) { cdf += term; term *= lambda / (double)(s + 1); }
+    return (double)f->g.nBins * std::max(0.0, 1.0 - cdf);
+}
 
 struct dy_reads
 {
@@ -694,6 +744,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
+            {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255},
             {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull},
         };
         for (auto & k : keys)
@@ -823,6 +874,7 @@ int dy_ibf_add(dy_ibf * f, const uint8_t * seq, uint64_t len, uint32_t bin)
         HIP_CHECK(hipMemcpyAsync(d.p, seq, len, hipMemcpyHostToDevice, ctx->stream));
         u64 nk = len - f->g.kmerSize + 1;
         u32 blocks = (u32)((nk + 255) / 256);
+        f->fillKnown = false;
         hipLaunchKernelGGL(k_ibf_insert, dim3(blocks), dim3(256), 0, ctx->stream, f->words.as<u64>(), f->g, d.as<u8>(), len, bin);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -844,6 +896,7 @@ int dy_ibf_clear_bins(dy_ibf * f, const uint32_t * bins, uint32_t n_bins)
         HIP_CHECK(hipSetDevice(ctx->device));
         DevBuf d; upload(d, mask);
         const u64 nTable = f->g.nHashPos * f->g.W;
+        f->fillKnown = false;
         hipLaunchKernelGGL(k_ibf_clear_bins, dim3(256 * 32), dim3(256), 0, ctx->stream, f->words.as<u64>(), nTable, f->g.W, d.as<u64>());
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -992,14 +1045,47 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         {
             HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
             const bool longReads = reads->maxLen >= 127 + f->g.kmerSize;
-            if (W == 1 || ctx->tune.ibfNarrow)
+            const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
+            u32 gShift = 0;
+            while ((1u << gShift) < W && gShift < 4) ++gShift;
+            const u32 G = 1u << gShift;
+            // LDS per wave of the two sweeps for W > 1 (see ibf_kernels.h)
+            const size_t hs = ((size_t)nKmax + 63) & ~(size_t)63;
+            const size_t lazyWave = (2 * hs + 128 + (size_t)nKmax * G + 49 * G) * 8;
+            const u32 listCap = 256;
+            const size_t eagerWave = (3 * hs + 33 * G + listCap + listCap / 4) * 8;
+            u32 kernel = 3;
+            if (W > 1 && !ctx->tune.ibfNarrow && nKmax >= 1 && nKmax <= 255)
+            {
+                kernel = (u32)ctx->tune.ibfKernel;
+                if (kernel == 0) kernel = ibfExpectedFalseCandidates(f, nKmax, threshold) < 0.5 ? 1 : 2;
+                if ((kernel == 1 && lazyWave > 60 * 1024) || (kernel == 2 && eagerWave > 60 * 1024)) kernel = 3;
+            }
+            if (kernel == 1 || kernel == 2)
+            {
+                const u32 slack = ibfSlack(f, nKmax, threshold);                // (the fill estimate may use the stream: the timed region starts behind it)
+                HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+                const size_t perWave = kernel == 1 ? lazyWave : eagerWave;
+                const u32 wavesPerBlock = perWave * 4 <= 32 * 1024 ? 4 : perWave * 2 <= 32 * 1024 ? 2 : 1;
+                const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+                if (kernel == 1)
+                    hipLaunchKernelGGL(k_ibf_query_lazy, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                       reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, slack);
+                else
+                    hipLaunchKernelGGL(k_ibf_query_eager2, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                                       reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, listCap);
+            }
+            else if (W == 1 || ctx->tune.ibfNarrow)
             {
                 const u32 wavesPerBlock = 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-                const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
                 if (W == 1 && nKmax > 64 && nKmax <= 127 && !ctx->tune.ibfFullTail)
+                {
+                    const u32 slack = ibfSlack(f, nKmax, threshold);
+                    HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
                     hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>());
+                                       reads->n, (u32)threshold, reads->masks.as<u64>(), slack);
+                }
                 else if (!longReads)
                     hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
@@ -1009,10 +1095,7 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
             }
             else
             {   // G = lanes per k-mer; LDS per wave = 64 hashes + the hash-0 words of as many k-mers as fit in ~19 KB
-                u32 gShift = 1;
-                while ((1u << gShift) < W && gShift < 4) ++gShift;
-                const u32 G = 1u << gShift;
-                const u32 nK = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
+                const u32 nK = nKmax;
                 const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
                 // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
                 const u32 ldsBudget = (u32)ctx->tune.ibfLdsKb * 1024;

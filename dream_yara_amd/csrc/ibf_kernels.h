@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
 // answers as k_ibf_query<7>; the second chunk of k-mers is fetched only as far as the decision needs it.
 __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ words, IbfGeom g,
                                                        const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
-                                                       u32 threshold, u64 * __restrict__ masks)
+                                                       u32 threshold, u64 * __restrict__ masks, u32 slack)
 {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -276,8 +276,13 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
         return;
     }
     const u32 nKmers = len - k + 1;             // at most 127, checked by the host for the whole batch
+    if (threshold > nKmers) { if (lane == 0) masks[read] = 0ull; return; }       // more hits needed than there are k-mers
     const u64 kMask = (1ull << k) - 1;
-    const u32 n0 = min(nKmers, 64u), tail = nKmers - n0;      // shorter reads of the batch simply have no tail
+    // first round: the k-mers after which a bin without hits is out of reach, plus `slack` for the false hits a bin collects by then
+    // (the host derives it from the filter's fill); at most 64 (one per lane), and the tail must fit the lanes too
+    u32 n0 = min(min(nKmers, 64u), max(threshold, nKmers - threshold + slack));
+    if (nKmers > 64 && n0 < nKmers - 64) n0 = nKmers - 64;
+    const u32 tail = nKmers - n0;               // shorter reads of the batch simply have no tail
     // The kernel is a chain of dependent gather rounds, so both strands go through every stage together: one round for the first
     // 64 k-mers of both, one per tail group of both, then the verification.
     // After the first 64 k-mers a bin is STRONG (count >= threshold: its verification can succeed on those k-mers alone), WEAK (it
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
     {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (weak[s]) { hashB[s] = laneKmerHash(seq, len, s, 64, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
+            if (weak[s]) { hashB[s] = laneKmerHash(seq, len, s, n0, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
         while ((weak[0] && fetched[0] < tail) || (weak[1] && fetched[1] < tail))
         {
 #pragma unroll
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
             {
                 if (chunk == 1 && fetched[s] < tail)
                 {   // the verification of a strong bin did not reach the threshold on the first 64 k-mers: complete the tail
-                    if (!haveHashB[s]) { hashB[s] = laneKmerHash(seq, len, s, 64, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
+                    if (!haveHashB[s]) { hashB[s] = laneKmerHash(seq, len, s, n0, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
                     if (lane >= fetched[s] && lane < tail) m1[s] = words[ibfWordIndex(g, hashB[s], 0)];
                     fetched[s] = tail;
                 }
@@ -669,6 +674,415 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
         }
         if (slot == 0 && wOk) out[w] = selW;
     }
+}
+
+// ---- K1 for more than 64 bins and reads of at most 255 k-mers ----------------------------------------------------------------------
+// Measured (scripts/ubench_gather.hip, profiles/r02_gather_ceiling.json): the chip serves 48-60 G independent random requests per
+// second whatever their width between 8 and 128 bytes.  A hash position of W <= 16 words is ONE request, so the cost of the sweep is
+// the NUMBER of (k-mer, hash function) positions it touches — and, right behind it, vector instructions.  Both kernels below
+//   * compute the position of a k-mer once per hash function, lane = k-mer (64 at a time), and share it through LDS: the G = pow2(W)
+//     lanes that serve one position read it back instead of redoing the 64-bit hash arithmetic;
+//   * count set bits (sparse: ~2 % of a column, plus the read's own bin) with LDS atomics, one u32 counter per bin, and let the atomic
+//     that lifts a counter to the bar of interest mark the bin in a per-word SUSPECT mask — decisions then look at the handful of
+//     suspects only, every lane for its own word, without any cross-lane reduction.
+// Same answers as whichBins (reference src/d_bloom_filter.h:161-224) for every input: each decision is exact, only the order of the
+// look-ups differs.
+//
+// k_ibf_query_lazy (thresholds high enough that false candidates are rare, e.g. 100 bp / threshold 29):
+//   phase A  hash function 0 only, k-mers in order, words kept in LDS.  After n k-mers a bin is ALIVE if count0 + (nK - n) >= threshold
+//            and STRONG if count0 >= threshold; the phase stops as soon as every alive bin is strong (after ~nK - threshold + slack
+//            k-mers only the read's own bin is left) or nothing is alive.
+//   phase B  the strong bins are verified lazily, k-mers in order: a position of hash function 1.. is fetched only while its word
+//            still carries an undecided bin; accepted once exact >= threshold, rejected once exact + unverified carriers + k-mers
+//            never looked at < threshold.  A single undecided bin has only as many carriers verified as it still needs, all
+//            remaining hash functions in one round.  K-mers beyond phase A are fetched on demand.
+//   100 bp / threshold 29 / 256 bins: ~62 + 62 + 2*29 = 182 positions per read instead of 2*83*3 = 498 (k_ibf_query_wide: 288).
+// k_ibf_query_eager2 (low thresholds, e.g. 150 bp / threshold 7 / 1024 bins: dozens of false candidate bins after one hash function,
+//   each of which k_ibf_query_lazy would have to refute through chains of dependent look-ups):
+//   stage 1  hash functions 0 AND 1 of every k-mer, fetched together (no dependency between any two requests), AND-ed: the
+//            survivors are the read's own bin plus ~0.5 false bits per k-mer; they are counted and the non-zero words kept in a list.
+//   stage 2  the suspects (count >= threshold: the read's own bin, practically) are verified against the remaining hash functions on
+//            their listed carriers, only as many as needed.
+//   150 bp / threshold 7: 532 + ~7 positions per read instead of 798 (k_ibf_query_wide: ~1330 requests).
+__device__ __forceinline__ u32 ldsByteGet(const u32 * __restrict__ c, u32 idx) { return (c[idx >> 2] >> (8 * (idx & 3))) & 0xffu; }
+__device__ __forceinline__ void ldsByteInc(u32 * __restrict__ c, u32 idx) { atomicAdd(&c[idx >> 2], 1u << (8 * (idx & 3))); }
+// every set bit of `bits` (a word of bins [binBase, binBase + 64)) bumps its bin's counter; the bump that reaches `bar` marks the bin
+__device__ __forceinline__ void countBitsMark(u32 * __restrict__ counters, u64 * __restrict__ suspectWord, u32 binBase, u64 bits, u32 bar)
+{
+    u32 lo = (u32)bits, hi = (u32)(bits >> 32);
+    while (lo) { const u32 b = (u32)__ffs((int)lo) - 1; lo &= lo - 1; if (atomicAdd(&counters[binBase + b], 1u) + 1 == bar) atomicOr((unsigned long long *)suspectWord, 1ull << b); }
+    while (hi) { const u32 b = (u32)__ffs((int)hi) + 31; hi &= hi - 1; if (atomicAdd(&counters[binBase + b], 1u) + 1 == bar) atomicOr((unsigned long long *)suspectWord, 1ull << b); }
+}
+__device__ __forceinline__ void countBitsBytes(u32 * __restrict__ counters, u32 binBase, u64 bits)
+{
+    while (bits) { const u32 b = (u32)__ffsll((long long)bits) - 1; bits &= bits - 1; ldsByteInc(counters, binBase + b); }
+}
+
+__global__ __launch_bounds__(256) void k_ibf_query_lazy(const u64 * __restrict__ words, IbfGeom g,
+                                                        const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
+                                                        u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 nKcap, u32 slack)
+{
+    extern __shared__ u64 ldsLazy[];
+    constexpr u32 UA = 8, UB = 4;   // sub-passes whose gathers are in flight together (phase A / phase B)
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (read >= nReads) return;
+    const u8 * seq = seqs + offs[read];
+    const u32 len = (u32)(offs[read + 1] - offs[read]);
+    const u32 k = g.kmerSize;
+    u64 * out = masks + (size_t)read * g.W;
+    const u32 nKmers = len >= k ? len - k + 1 : 0;
+    if (nKmers == 0 || threshold == 0 || threshold > nKmers)
+    {   // no k-mer: every count is 0; threshold 0 selects every bin; more hits needed than there are k-mers: none
+        for (u32 w = lane; w < g.W; w += 64)
+        {
+            const u32 left = g.nBins - w * 64;
+            out[w] = threshold == 0 ? (left >= 64 ? ~0ull : ((1ull << left) - 1)) : 0ull;
+        }
+        return;
+    }
+    const u64 kMask = (1ull << k) - 1;
+    const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
+    const u32 hashSlots = (nKcap + 63) & ~63u;
+    // LDS per wave: k-mer hashes | positions of hash function 0 | positions of the round's window under two further hash functions |
+    // hash-0 words w0c[kmer * G + word] | cnt0: u32 per (word, bin), hash-0 hits among the k-mers of phase A | exc, seen: bytes per
+    // (word, bin), exact hits among the verified carriers / verified carriers of phase A | suspect mask per word
+    const size_t perWave = 2 * (size_t)hashSlots + 128 + (size_t)nKcap * G + 32 * G + 16 * G + G;
+    u64 * myHash = ldsLazy + (size_t)wave * perWave;
+    u64 * myPos0 = myHash + hashSlots;
+    u64 * myPosX = myPos0 + hashSlots;                // [2][64]
+    u64 * w0c = myPosX + 128;
+    u32 * cnt0 = (u32 *)(w0c + (size_t)nKcap * G);    // 64 G counters
+    u32 * exc = cnt0 + 64 * G;                        // 16 G words of 4 byte counters
+    u32 * seen = exc + 16 * G;
+    u64 * susp = (u64 *)(seen + 16 * G);              // G words
+
+    for (u32 w0 = 0; w0 < g.W; w0 += G)
+    {
+        const u32 w = w0 + wl;
+        const bool wOk = w < g.W;
+        const u32 left = wOk ? g.nBins - w * 64 : 0;
+        const u64 binMask = left >= 64 ? ~0ull : ((1ull << left) - 1);
+        u64 selW = 0;
+        for (u32 strand = 0; strand < 2; ++strand)
+        {
+            const bool firstIsN = strandCode(seq, len, 0, strand) > 3;
+            __builtin_amdgcn_wave_barrier();
+            for (u32 h0 = 0; h0 < nKmers; h0 += 64)
+            {
+                const u64 h = laneKmerHash(seq, len, strand, h0, lane, k, kMask, firstIsN);
+                myHash[h0 + lane] = h;
+                myPos0[h0 + lane] = ibfWordIndex(g, h, 0);
+            }
+            for (u32 i = lane; i < (64 + 32) * G + 2 * G; i += 64) cnt0[i] = 0;      // cnt0, exc, seen, susp are contiguous
+            __builtin_amdgcn_wave_barrier();
+            // ---- phase A
+            // first stop where the false bins are expected to have died (slack = false hits a bin may collect by then), then every 8 k-mers
+            const u32 n1 = min(nKmers, max(nKmers - threshold + slack, threshold));
+            const u32 bar1 = threshold - (nKmers - n1);           // >= 1: a bin below it at any stop is out of reach
+            u32 fetched = 0;
+            u64 strong = 0;
+            bool anyStrong = false;
+            for (;;)
+            {
+                const u32 target = fetched == 0 ? n1 : min(nKmers, fetched + 8u);
+                for (u32 kb = fetched; kb < target; kb += UA * slots)
+                {
+                    u64 m[UA];
+#pragma unroll
+                    for (u32 u = 0; u < UA; ++u)
+                    {
+                        const u32 kk = kb + u * slots + slot;
+                        m[u] = (kk < target && wOk) ? words[myPos0[kk] + w] : 0;
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < UA; ++u)
+                    {
+                        const u32 kk = kb + u * slots + slot;
+                        if (kk < target) w0c[(size_t)kk * G + wl] = m[u];
+                        countBitsMark(cnt0, susp + wl, wl * 64, m[u] & binMask, bar1);
+                    }
+                }
+                fetched = target;
+                __builtin_amdgcn_wave_barrier();
+                // every lane decides for its own word (the lanes of the other slots do the same work on the same data)
+                const u32 rest = nKmers - fetched;
+                u64 alive = 0; strong = 0;
+                for (u64 todo = susp[wl]; todo; todo &= todo - 1)
+                {
+                    const u32 b = (u32)__ffsll((long long)todo) - 1;
+                    const u32 c = cnt0[wl * 64 + b];
+                    if (c + rest >= threshold) alive |= 1ull << b;
+                    if (c >= threshold) strong |= 1ull << b;
+                }
+                anyStrong = ballot64(strong != 0) != 0;
+                if (ballot64(alive != 0) == 0) { anyStrong = false; break; }
+                if (fetched == nKmers || ballot64((alive & ~strong) != 0) == 0) break;
+            }
+            if (!anyStrong) continue;
+            // ---- phase B: lazy verification of the strong bins.  K-mers [0, processed) are done with: every carrier of an undecided bin
+            // among them has been verified.  bound(bin) = exact + unverified carriers of phase A + k-mers never looked at.
+            u64 und = strong;                         // undecided bins of word wl (the same in every slot)
+            u32 processed = 0;
+            while (processed < nKmers)
+            {
+                const u64 undLanes = ballot64(und != 0 && slot == 0);
+                if (undLanes == 0) break;
+                // a single undecided bin: verify only as many of its carriers as it still needs, all remaining hash functions at once
+                u32 need = 0xFFFFFFFFu;
+                if ((undLanes & (undLanes - 1)) == 0)
+                {
+                    const u32 ownerLane = (u32)__ffsll((long long)undLanes) - 1;          // slot 0: ownerLane = the bin's word
+                    const u32 lo = __shfl((u32)und, (int)ownerLane, 64), hi = __shfl((u32)(und >> 32), (int)ownerLane, 64);
+                    const u64 uo = ((u64)hi << 32) | lo;
+                    if ((uo & (uo - 1)) == 0) need = threshold - ldsByteGet(exc, ownerLane * 64 + (u32)__ffsll((long long)uo) - 1);
+                }
+                // a round looks at up to 64 k-mers; their positions under the next two hash functions, lane = k-mer
+                const u32 span = min(64u, UB * slots);
+                const u32 lastK = min(nKmers, processed + span);
+                __builtin_amdgcn_wave_barrier();
+                if (g.nHashes > 1 && processed + lane < lastK)
+                {
+                    const u64 h = myHash[processed + lane];
+                    myPosX[lane] = ibfWordIndex(g, h, 1);
+                    if (g.nHashes > 2) myPosX[64 + lane] = ibfWordIndex(g, h, 2);
+                }
+                __builtin_amdgcn_wave_barrier();
+                u32 nextK = lastK;
+                u64 c[UB];
+                u32 taken = 0;
+#pragma unroll
+                for (u32 u = 0; u < UB; ++u)
+                {
+                    const u32 kk = processed + u * slots + slot;
+                    u64 m0 = 0;
+                    if (u * slots < span && kk < lastK && und != 0) m0 = kk < fetched ? w0c[(size_t)kk * G + wl] : words[myPos0[kk] + w];
+                    c[u] = m0 & und;
+                    if (need != 0xFFFFFFFFu)
+                    {   // the carriers of the single bin in k-mer order = this sub-pass's lanes in lane order (one lane per k-mer carries its word)
+                        const u64 car = ballot64(c[u] != 0);
+                        const u32 pc = (u32)__popcll(car);
+                        if (taken + (u32)__popcll(car & ((1ull << lane) - 1)) >= need) c[u] = 0;
+                        if (taken < need && taken + pc >= need)
+                        {   // the need-th carrier sits in this sub-pass: the round ends behind its k-mer
+                            u64 t = car;
+                            for (u32 i = taken + 1; i < need; ++i) t &= t - 1;
+                            nextK = processed + u * slots + (((u32)__ffsll((long long)t) - 1) >> gShift) + 1;
+                        }
+                        taken += pc;
+                    }
+                }
+#pragma unroll
+                for (u32 u = 0; u < UB; ++u)
+                    if (processed + u * slots + slot < fetched) countBitsBytes(seen, wl * 64, c[u]);
+                if (need != 0xFFFFFFFFu && g.nHashes == 3)
+                {
+                    u64 v1[UB], v2[UB];
+#pragma unroll
+                    for (u32 u = 0; u < UB; ++u)
+                    {
+                        v1[u] = c[u] ? words[myPosX[u * slots + slot] + w] : 0;
+                        v2[u] = c[u] ? words[myPosX[64 + u * slots + slot] + w] : 0;
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < UB; ++u) c[u] &= v1[u] & v2[u];
+                }
+                else
+                    for (u32 hf = 1; hf < g.nHashes; ++hf)
+                    {
+                        u64 v[UB];
+#pragma unroll
+                        for (u32 u = 0; u < UB; ++u)
+                        {
+                            v[u] = 0;
+                            if (c[u]) v[u] = words[(hf <= 2 ? myPosX[(hf - 1) * 64 + u * slots + slot] : ibfWordIndex(g, myHash[processed + u * slots + slot], hf)) + w];
+                        }
+#pragma unroll
+                        for (u32 u = 0; u < UB; ++u) c[u] &= v[u];
+                    }
+#pragma unroll
+                for (u32 u = 0; u < UB; ++u) countBitsBytes(exc, wl * 64, c[u]);
+                processed = nextK;
+                __builtin_amdgcn_wave_barrier();
+                const u32 unlooked = nKmers - max(fetched, processed);
+                for (u64 todo = und; todo; todo &= todo - 1)
+                {
+                    const u32 b = (u32)__ffsll((long long)todo) - 1;
+                    const u32 e = ldsByteGet(exc, wl * 64 + b);
+                    if (e >= threshold) { selW |= 1ull << b; und &= ~(1ull << b); }
+                    else if (e + (cnt0[wl * 64 + b] - ldsByteGet(seen, wl * 64 + b)) + unlooked < threshold) und &= ~(1ull << b);
+                }
+            }
+        }
+        if (slot == 0 && wOk) out[w] = selW;
+    }
+}
+
+// see the comment above k_ibf_query_lazy.  LDS per wave: hashes | positions under hash functions 0 and 1 | u32 counters | suspect
+// masks | list of the non-zero AND-ed words: (k-mer << 4 | word) keys + values.
+__global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict__ words, IbfGeom g,
+                                                          const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
+                                                          u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 nKcap, u32 listCap)
+{
+    extern __shared__ u64 ldsEager[];
+    constexpr u32 U = 8;            // sub-passes in flight (two gathers each): the kernel is a chain of dependent batches, the fewer the better
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (read >= nReads) return;
+    const u8 * seq = seqs + offs[read];
+    const u32 len = (u32)(offs[read + 1] - offs[read]);
+    const u32 k = g.kmerSize;
+    u64 * out = masks + (size_t)read * g.W;
+    const u32 nKmers = len >= k ? len - k + 1 : 0;
+    if (nKmers == 0 || threshold == 0 || threshold > nKmers)
+    {
+        for (u32 w = lane; w < g.W; w += 64)
+        {
+            const u32 left = g.nBins - w * 64;
+            out[w] = threshold == 0 ? (left >= 64 ? ~0ull : ((1ull << left) - 1)) : 0ull;
+        }
+        return;
+    }
+    const u64 kMask = (1ull << k) - 1;
+    const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
+    const u32 hashSlots = (nKcap + 63) & ~63u;
+    const size_t perWave = 3 * (size_t)hashSlots + 32 * G + G + listCap + listCap / 4;
+    u64 * myHash = ldsEager + (size_t)wave * perWave;
+    u64 * myPos0 = myHash + hashSlots;
+    u64 * myPos1 = myPos0 + hashSlots;
+    u32 * cnt = (u32 *)(myPos1 + hashSlots);          // 64 G counters: k-mers whose hash-0 AND hash-1 words both carry the bin
+    u64 * susp = (u64 *)(cnt + 64 * G);               // G words
+    u64 * listVal = susp + G;                         // listCap AND-ed words
+    u16 * listKey = (u16 *)(listVal + listCap);       // listCap keys: k-mer << 4 | word
+    const u32 stage1 = g.nHashes >= 2 ? 2 : 1;
+
+    for (u32 w0 = 0; w0 < g.W; w0 += G)
+    {
+        const u32 w = w0 + wl;
+        const bool wOk = w < g.W;
+        const u32 left = wOk ? g.nBins - w * 64 : 0;
+        const u64 binMask = left >= 64 ? ~0ull : ((1ull << left) - 1);
+        u64 selW = 0;
+        for (u32 strand = 0; strand < 2; ++strand)
+        {
+            const bool firstIsN = strandCode(seq, len, 0, strand) > 3;
+            __builtin_amdgcn_wave_barrier();
+            for (u32 h0 = 0; h0 < nKmers; h0 += 64)
+            {
+                const u64 h = laneKmerHash(seq, len, strand, h0, lane, k, kMask, firstIsN);
+                myHash[h0 + lane] = h;
+                myPos0[h0 + lane] = ibfWordIndex(g, h, 0);
+                if (stage1 == 2) myPos1[h0 + lane] = ibfWordIndex(g, h, 1);
+            }
+            for (u32 i = lane; i < 64 * G + 2 * G; i += 64) cnt[i] = 0;       // cnt and susp are contiguous
+            __builtin_amdgcn_wave_barrier();
+            // ---- stage 1: every k-mer, hash functions 0 and 1 together
+            u32 nList = 0;
+            bool overflow = false;
+            for (u32 kb = 0; kb < nKmers; kb += U * slots)
+            {
+                u64 a[U], b1[U];
+#pragma unroll
+                for (u32 u = 0; u < U; ++u)
+                {
+                    const u32 kk = kb + u * slots + slot;
+                    const bool valid = kk < nKmers && wOk;
+                    a[u] = valid ? words[myPos0[kk] + w] : 0;
+                    b1[u] = (valid && stage1 == 2) ? words[myPos1[kk] + w] : ~0ull;
+                }
+#pragma unroll
+                for (u32 u = 0; u < U; ++u)
+                {
+                    const u32 kk = kb + u * slots + slot;
+                    const u64 v = a[u] & b1[u] & binMask;
+                    countBitsMark(cnt, susp + wl, wl * 64, v, threshold);
+                    const u64 have = ballot64(v != 0);
+                    if (have)
+                    {
+                        const u32 pos = nList + (u32)__popcll(have & ((1ull << lane) - 1));
+                        if (v != 0 && pos < listCap) { listVal[pos] = v; listKey[pos] = (u16)((kk << 4) | wl); }
+                        nList += (u32)__popcll(have);
+                    }
+                }
+            }
+            if (nList > listCap) { overflow = true; nList = listCap; }
+            __builtin_amdgcn_wave_barrier();
+            if (ballot64(susp[wl] != 0) == 0) continue;                      // no bin reaches the threshold even on two hash functions
+            if (g.nHashes <= stage1)
+            {   // nothing left to verify: the counts are exact
+                selW |= susp[wl];
+                continue;
+            }
+            // ---- stage 2: the suspects against the remaining hash functions, one suspect at a time (there is normally one)
+            for (u32 ow = 0; ow < G; ++ow)
+            {
+                u64 todo = susp[ow];
+                while (todo)
+                {
+                    const u32 b = (u32)__ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const u32 carriers = cnt[ow * 64 + b];
+                    u32 exact = 0, seenC = 0;
+                    bool decided = false, accepted = false;
+                    if (!overflow)
+                        for (u32 l0 = 0; l0 < nList && !decided; l0 += 64)
+                        {
+                            const u32 li = l0 + lane;
+                            bool car = false; u32 key = 0;
+                            if (li < nList) { key = listKey[li]; car = (key & 15) == ow && ((listVal[li] >> b) & 1); }
+                            u64 pending = ballot64(car);
+                            while (pending && !decided)
+                            {
+                                const u32 need = threshold - exact;
+                                const bool act = ((pending >> lane) & 1) && (u32)__popcll(pending & ((1ull << lane) - 1)) < need;
+                                bool hit = act;
+                                if (act)
+                                {
+                                    const u64 h = myHash[key >> 4];
+                                    for (u32 hf = stage1; hf < g.nHashes; ++hf) hit = hit && ((words[ibfWordIndex(g, h, hf) + w0 + ow] >> b) & 1);
+                                }
+                                const u64 actMask = ballot64(act);
+                                exact += (u32)__popcll(ballot64(hit));
+                                seenC += (u32)__popcll(actMask);
+                                pending &= ~actMask;
+                                if (exact >= threshold) { decided = true; accepted = true; }
+                                else if (exact + (carriers - seenC) < threshold) decided = true;
+                            }
+                        }
+                    else
+                    {   // the list overflowed (pathological: hundreds of surviving words): plain sweep over every k-mer for this bin
+                        for (u32 kb = 0; kb < nKmers && !decided; kb += 64)
+                        {
+                            const u32 kk = kb + lane;
+                            bool hit = false;
+                            if (kk < nKmers)
+                            {
+                                hit = true;
+                                const u64 h = myHash[kk];
+                                for (u32 hf = 0; hf < g.nHashes && hit; ++hf) hit = (words[ibfWordIndex(g, h, hf) + w0 + ow] >> b) & 1;
+                            }
+                            exact += (u32)__popcll(ballot64(hit));
+                            const u32 restK = nKmers - min(nKmers, kb + 64);
+                            if (exact >= threshold) { decided = true; accepted = true; }
+                            else if (exact + restK < threshold) decided = true;
+                        }
+                    }
+                    if (accepted && wl == ow) selW |= 1ull << b;
+                }
+            }
+        }
+        if (slot == 0 && wOk) out[w] = selW;
+    }
+}
+
+// Set bits in an evenly spread sample of the table's words (the filter's fill decides where the sweeps place their first check)
+__global__ void k_ibf_fill_sample(const u64 * __restrict__ words, u64 nTableWords, u32 nSamples, unsigned long long * __restrict__ total)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 0;
+    if (t < nSamples) c = (u32)__popcll(words[(u64)(((unsigned __int128)t * nTableWords) / nSamples)]);
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
 }
 
 // Insertion: thread per k-mer (reference src/d_bloom_filter.h:293-315). seq = Dna5 codes on the device.

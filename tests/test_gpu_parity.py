@@ -182,6 +182,46 @@ def test_ibf_low_thresholds_many_false_candidates(dy, ctx, ob, tmp_path, bins, b
     rd.close(); ibf.close(); oibf.close()
 
 
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("bins,bits,k,hashes", [(1024, 1 << 27, 12, 3), (192, 1 << 24, 11, 3), (256, 1 << 21, 10, 3), (130, 1 << 23, 16, 5), (200, 1 << 25, 14, 2), (256, 1 << 24, 13, 1)])
+def test_ibf_every_wide_sweep_matches_oracle(dy, ob, tmp_path, kernel, bins, bits, k, hashes):
+    """More than 64 bins: each of the three sweeps forced in turn (dy_ctx_set_tuning ibf_kernel: 1 = k_ibf_query_lazy, 2 = k_ibf_query_eager2,
+    3 = k_ibf_query_wide; 0 = automatic choice from the filter fill is what every other test runs) over sparse, dense and saturated filters
+    (the smallest overflows eager2's list and takes its plain sweep), 1 / 2 / 3 / 5 hash functions, reads from 0 to 254 k-mers with Ns,
+    every threshold from 1 to beyond the k-mer count, and a forced first-check position (ibf_slack) that makes phase A resume."""
+    rng = np.random.default_rng(bins + k + hashes)
+    genomes = [rng.integers(0, 4, 20000, dtype=np.uint8) for _ in range(bins)]
+    goffs = np.arange(bins + 1, dtype=np.uint64) * np.uint64(20000)
+    path = str(tmp_path / "f.filter")
+    ob.build_filter(path, bins, hashes, k, bits, np.concatenate(genomes), goffs)
+    reads = []
+    for i in range(500):
+        b = int(rng.integers(0, bins)); L = int(rng.integers(0, k + 254)); s = int(rng.integers(0, 20000 - L))
+        r = genomes[b][s:s + L].copy()
+        for _ in range(int(rng.integers(0, 6))):
+            if L: r[int(rng.integers(0, L))] = rng.integers(0, 4)
+        if i % 4 == 0 and L > 40: r[L // 2:] = rng.integers(0, 4, L - L // 2)      # half of the read matches: bins that die late or survive narrowly
+        if i % 9 == 0 and L: r[int(rng.integers(0, L))] = 4
+        if i % 13 == 0 and L: r[0] = 4
+        if i % 2: r = np.where(r[::-1] < 4, 3 - r[::-1], 4).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    oibf = ob.OracleIbf(path)
+    want = {thr: oibf.query(codes, offs, thr, threads=8) for thr in (0, 1, 3, 7, 15, 29, 40, 90, 200, 254, 300)}
+    oibf.close()
+    for slack in (0, 1):
+        tctx = dy.Context(0)
+        try:
+            tctx.set_tuning("ibf_kernel", kernel)
+            tctx.set_tuning("ibf_slack", slack)
+            ibf = dy.Ibf.load(tctx, path); rd = dy.Reads(tctx, codes, offs)
+            for thr, m in want.items():
+                assert np.array_equal(ibf.query(rd, thr), m), (thr, slack)
+            rd.close(); ibf.close()
+        finally:
+            tctx.close()
+
+
 def test_large_batch_upload_equals_small_batches(dy, ctx, ob, tmp_path):
     """dy_reads_upload stages batches above 32 MB through pinned memory on several threads (8 MB chunks); the bin masks of one
     40 MB batch must equal those of the same reads uploaded in small batches (plain copy path), and a sample must equal the oracle."""
