@@ -47,7 +47,16 @@ class ReadResult(C.Structure):
 class MapStats(C.Structure):
     _fields_ = [("items", C.c_uint64), ("raw_matches", C.c_uint64), ("hard_items", C.c_uint64), ("pool_retries", C.c_uint64),
                 ("ms_ibf", C.c_double), ("ms_items", C.c_double), ("ms_search", C.c_double), ("ms_extend", C.c_double),
-                ("ms_finalize", C.c_double)]
+                ("ms_finalize", C.c_double), ("ibf_kernel", C.c_uint32), ("ibf_slack", C.c_uint32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_bins", C.c_uint32), ("n_bins_resident", C.c_uint32), ("n_contigs", C.c_uint32), ("prefix_q", C.c_uint32), ("total_rows", C.c_uint64),
+                ("bytes_rank", C.c_uint64), ("bytes_sparse_sa", C.c_uint64), ("bytes_contigs", C.c_uint64), ("bytes_expanded_sa", C.c_uint64),
+                ("bytes_prefix_table", C.c_uint64), ("bytes_isa_and_text", C.c_uint64)]
+
+
+IBF_KERNEL_NAMES = {0: None, 1: "k_ibf_query_two", 2: "k_ibf_query<7>", 3: "k_ibf_query<14>", 4: "k_ibf_query_lazy", 5: "k_ibf_query_eager2", 6: "k_ibf_query_wide"}
 
 
 MATCH_DTYPE = np.dtype([("contig", "<u4"), ("begin", "<u4"), ("length", "<u2"), ("errors", "u1"), ("is_rev", "u1")])
@@ -83,6 +92,7 @@ SYMBOLS = [
     ("dy_index_contigs", C.c_uint32, [_P]),
     ("dy_index_contig_name", C.c_char_p, [_P, C.c_uint32]),
     ("dy_index_contig_length", C.c_uint64, [_P, C.c_uint32]),
+    ("dy_index_get_info", C.c_int, [_P, C.POINTER(IndexInfo)]),
     ("dy_index_free", None, [_P]),
     ("dy_params_default", None, [C.POINTER(Params)]),
     ("dy_map_reads", C.c_int, [_P, _P, _P, C.POINTER(Params), C.POINTER(_P)]),
@@ -277,6 +287,11 @@ class Index:
             _check(self.lib.dy_index_load_sharded(ctx.h, os.fsencode(directory), n_bins, owned.ctypes.data, C.byref(h)))
         self.h = h
         self.n_bins = n_bins
+
+    def info(self):
+        i = IndexInfo()
+        _check(self.lib.dy_index_get_info(self.h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in IndexInfo._fields_}
 
     def contig_names(self):
         return [self.lib.dy_index_contig_name(self.h, c).decode() for c in range(self.lib.dy_index_contigs(self.h))]

@@ -1068,6 +1068,7 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 const size_t perWave = kernel == 1 ? lazyWave : eagerWave;
                 const u32 wavesPerBlock = perWave * 4 <= 32 * 1024 ? 4 : perWave * 2 <= 32 * 1024 ? 2 : 1;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+                ctx->stats.ibf_kernel = kernel == 1 ? 4 : 5; ctx->stats.ibf_slack = slack;
                 if (kernel == 1)
                     hipLaunchKernelGGL(k_ibf_query_lazy, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, slack);
@@ -1083,19 +1084,27 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 {
                     const u32 slack = ibfSlack(f, nKmax, threshold);
                     HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+                    ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack;
                     hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>(), slack);
                 }
                 else if (!longReads)
+                {
+                    ctx->stats.ibf_kernel = 2;
                     hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
+                }
                 else
+                {
+                    ctx->stats.ibf_kernel = 3;
                     hipLaunchKernelGGL(k_ibf_query<14>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
+                }
             }
             else
             {   // G = lanes per k-mer; LDS per wave = 64 hashes + the hash-0 words of as many k-mers as fit in ~19 KB
                 const u32 nK = nKmax;
+                ctx->stats.ibf_kernel = 6;
                 const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
                 // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
                 const u32 ldsBudget = (u32)ctx->tune.ibfLdsKb * 1024;
@@ -1241,6 +1250,20 @@ uint32_t dy_index_bins(const dy_index * idx) { return idx ? (uint32_t)idx->bins.
 uint32_t dy_index_contigs(const dy_index * idx) { return idx ? (uint32_t)idx->contigNames.size() : 0; }
 const char * dy_index_contig_name(const dy_index * idx, uint32_t c) { return (idx && c < idx->contigNames.size()) ? idx->contigNames[c].c_str() : nullptr; }
 uint64_t dy_index_contig_length(const dy_index * idx, uint32_t c) { return (idx && c < idx->contigLengths.size()) ? idx->contigLengths[c] : 0; }
+int dy_index_get_info(const dy_index * idx, dy_index_info * info)
+{
+    if (!idx || !info) { g_lastError = "NULL argument"; return DY_EINVAL; }
+    memset(info, 0, sizeof(*info));
+    info->n_bins = (uint32_t)idx->bins.size(); info->n_contigs = (uint32_t)idx->contigNames.size(); info->prefix_q = idx->prefixQ;
+    u64 rows = 0; u32 resident = 0;
+    for (auto & b : idx->bins) { rows += b.n; resident += b.n ? 1 : 0; }
+    info->n_bins_resident = resident; info->total_rows = rows;
+    info->bytes_rank = idx->rank.cap; info->bytes_sparse_sa = idx->ind.cap + idx->valOffset.cap + idx->valContig.cap; info->bytes_contigs = idx->contigs.cap;
+    info->bytes_expanded_sa = idx->hasFullSa ? idx->saFullOffset.cap + idx->saFullContig.cap : 0;
+    info->bytes_prefix_table = idx->prefixQ ? idx->prefixTable.cap : 0;
+    info->bytes_isa_and_text = idx->hasIsa ? idx->isa.cap + idx->ftext.cap : 0;
+    return DY_OK;
+}
 void dy_index_free(dy_index * idx) { if (idx) { (void)hipSetDevice(idx->ctx->device); delete idx; } }
 
 // ---- mapping ------------------------------------------------------------------------------------------

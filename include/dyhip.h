@@ -120,6 +120,15 @@ uint32_t dy_index_bins(const dy_index *idx);
 uint32_t dy_index_contigs(const dy_index *idx);                       /* over all bins */
 const char *dy_index_contig_name(const dy_index *idx, uint32_t c);    /* global contig id, bin order */
 uint64_t dy_index_contig_length(const dy_index *idx, uint32_t c);
+/* What is resident for the index (observability; the device-only tables are sized from the free HBM at load). */
+typedef struct {
+    uint32_t n_bins, n_bins_resident;   /* bins in the directory / bins whose FM structures are on this device */
+    uint32_t n_contigs, prefix_q;       /* q of the q-mer range table (0 = none) */
+    uint64_t total_rows;                /* BWT rows over the resident bins */
+    uint64_t bytes_rank, bytes_sparse_sa, bytes_contigs;                    /* the reference's own structures (lf.drv, sa.*, txt.concat unpacked) */
+    uint64_t bytes_expanded_sa, bytes_prefix_table, bytes_isa_and_text;     /* device-only accelerators, 0 when not built */
+} dy_index_info;
+int  dy_index_get_info(const dy_index *idx, dy_index_info *info);
 void dy_index_free(dy_index *idx);
 
 /* ---- mapping ----------------------------------------------------------------------------------------- */
@@ -184,6 +193,9 @@ typedef struct {
     uint64_t pool_retries;   /* times the match pool had to grow */
     double   ms_ibf;         /* K1 of the last dy_ibf_query on this context (hipEvent on the context's stream) */
     double   ms_items, ms_search, ms_extend, ms_finalize;   /* device time per stage of the last dy_map_reads */
+    uint32_t ibf_kernel;     /* sweep the last dy_ibf_query ran: 1 k_ibf_query_two, 2 k_ibf_query<7>, 3 k_ibf_query<14>, 4 k_ibf_query_lazy,
+                                5 k_ibf_query_eager2, 6 k_ibf_query_wide (0 = none yet) */
+    uint32_t ibf_slack;      /* first check of that sweep at nK - threshold + slack k-mers (derived from the sampled filter fill) */
 } dy_map_stats;
 int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
 
