@@ -73,7 +73,9 @@ inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = t
     MappedFile size(prefix + ".txt.size");
     if (size.size() != 24) throw IoError("Error while opening reference file.");
     u64 nContigs = loadLE<u64>(size.data() + 8), sum = loadLE<u64>(size.data() + 16);
-    if (nContigs == 0 || nContigs > 255) throw IoError("bins with 0 or more than 255 contigs are not supported (" + prefix + ")");
+    // more than 65535 contigs per bin need the reference's DR_YARA_LARGE_CONTIGS build (src/d_indexer.cpp:376-382)
+    if (nContigs == 0) throw IoError("Error while opening reference file.");
+    if (nContigs > 65535) throw IoError("Maximum number of contigs exceeded. Recompile with -DDR_YARA_LARGE_CONTIGS=ON. (" + prefix + ")");
     d.nContigs = (u32)nContigs;
     d.contigIdBase = (u32)H.contigNames.size();
 
@@ -120,9 +122,29 @@ inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = t
         if (d.n >= 0xFFFE0000u) throw IoError("bins above 4.29 Gbp are not supported (" + prefix + ")");      // rows must stay below the DIRECT_* tags
         for (int c = 0; c < 4; ++c) d.pst[c] = loadLE<u32>(pst.data() + 4 * c);
         d.drs = drs.data()[0];
-        if (drp.size() != nContigs * 4) throw IoError("unexpected lf.drp size in " + prefix);
+        // The indexer types an index by the bin's OWN contig count (reference src/d_indexer.cpp:366-383): up to 255 contigs -> uint8_t ids
+        // and the sentinel rows as a plain position list (Naive dictionary, src/misc_types.h:165-167); up to 65535 -> uint16_t ids and a
+        // Levels bool dictionary over the rows — the type of sa.ind, hence its layout: 8 bytes per 32 rows, [u32 bits, row j at bit
+        // 31-j][u32 set bits before].  Either way the device gets the ascending list of sentinel rows.  (The reference MAPPER types all
+        // bins by the contig count summed over the bins, src/d_mapper.cpp:437-472, so it cannot read a mixed set its own indexer wrote;
+        // here every bin is read the way it was written.)  Parity unpinned: the gold bins hold one contig each.
         d.drpOff = (u32)H.drp.size();
-        for (u64 i = 0; i < nContigs; ++i) H.drp.push_back(loadLE<u32>(drp.data() + 4 * i));
+        if (nContigs <= 255)
+        {
+            if (drp.size() != nContigs * 4) throw IoError("unexpected lf.drp size in " + prefix);
+            for (u64 i = 0; i < nContigs; ++i) H.drp.push_back(loadLE<u32>(drp.data() + 4 * i));
+        }
+        else
+        {
+            if (drp.size() != ((size_t)d.n + 31) / 32 * 8) throw IoError("unexpected lf.drp size in " + prefix);
+            u64 found = 0;
+            for (size_t e = 0; e * 8 < drp.size(); ++e)
+            {
+                const u32 bits = loadLE<u32>(drp.data() + e * 8);
+                for (u32 t = 0; t < 32; ++t) if ((bits >> (31 - t)) & 1) { H.drp.push_back((u32)(e * 32 + t)); ++found; }
+            }
+            if (found != nContigs) throw IoError("lf.drp does not hold one sentinel per contig in " + prefix);
+        }
         // rank blocks; rank(.., n) with n % 64 == 0 touches one block past the file: synthesise it
         d.rankOff = H.rank.size() / 32;
         size_t nblk = drv.size() / 32;
@@ -141,14 +163,15 @@ inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = t
         d.indOff = H.ind.size() / 8;
         if (ind.size() / 8 * 32 < d.n) throw IoError("sa.ind too short in " + prefix);
         H.ind.insert(H.ind.end(), ind.data(), ind.data() + ind.size());
-        // sa.val: packed (u8 contig, u32 offset) for bins with <= 255 contigs (reference src/misc_types.h:184-188)
-        if (val.size() % 5) throw IoError("unexpected sa.val record size in " + prefix);
+        // sa.val: packed Pair<contig id, u32 offset> (reference src/misc_types.h:184-188): 5 bytes with u8 ids, 6 bytes with u16 ids
+        const size_t idBytes = nContigs <= 255 ? 1 : 2, rec = idBytes + 4;
+        if (val.size() % rec) throw IoError("unexpected sa.val record size in " + prefix);
         d.valOff = H.valOffset.size();
-        size_t nval = val.size() / 5;
+        size_t nval = val.size() / rec;
         for (size_t i = 0; i < nval; ++i)
         {
-            H.valContig.push_back(val.data()[i * 5]);
-            H.valOffset.push_back(loadLE<u32>(val.data() + i * 5 + 1));
+            H.valContig.push_back(idBytes == 1 ? (u16)val.data()[i * rec] : loadLE<u16>(val.data() + i * rec));
+            H.valOffset.push_back(loadLE<u32>(val.data() + i * rec + idBytes));
         }
     }
     H.bins.push_back(d);

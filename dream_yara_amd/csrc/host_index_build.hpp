@@ -44,7 +44,7 @@ inline std::vector<FastaRecord> readFasta(const std::string & path)
 
 // Suffix array of t[0..n), symbols in [0, sigma).  Every contig ends with its own sentinel value, so no two suffixes
 // compare equal and comparisons never run past a sentinel.
-inline std::vector<u32> suffixArrayDoubling(const std::vector<u16> & t, u32 sigma)
+inline std::vector<u32> suffixArrayDoubling(const std::vector<u32> & t, u32 sigma)
 {
     const u32 n = (u32)t.size();
     u32 bits = 1; while ((1u << bits) <= sigma) ++bits;       // symbols are shifted by +1; 0 pads beyond the end
@@ -109,7 +109,8 @@ inline BuiltBin buildBin(const std::vector<FastaRecord> & recs)
 {
     BuiltBin B;
     B.count = recs.size();
-    if (B.count == 0 || B.count > 255) throw IoError("a bin must hold between 1 and 255 contigs");
+    if (B.count == 0) throw IoError("a bin must hold at least one contig");
+    if (B.count > 65535) throw IoError("Maximum number of contigs exceeded. Recompile with -DDR_YARA_LARGE_CONTIGS=ON.");      // reference src/d_indexer.cpp:376-382
     B.limits.push_back(0); B.nameLimits.push_back(0);
     for (auto & r : recs)
     {
@@ -126,7 +127,7 @@ inline BuiltBin buildBin(const std::vector<FastaRecord> & recs)
     B.n = n;
 
     // text = reverse(randomizeNs(contig_c)) $c ...   symbols: $c -> c, base b -> cnt + b
-    std::vector<u16> T(n);
+    std::vector<u32> T(n);
     std::vector<u32> start(cnt + 1);
     {
         std::mt19937 rng(0xDEADBEEF);                                // one generator per bin, reference src/store_seqs.h:244-252
@@ -137,8 +138,8 @@ inline BuiltBin buildBin(const std::vector<FastaRecord> & recs)
             start[c] = p;
             std::vector<u8> tmp(B.concat.begin() + lo, B.concat.begin() + lo + len);
             for (auto & x : tmp) if (x > 3) x = (u8)(rng() % 4);
-            for (u64 i = 0; i < len; ++i) T[p++] = (u16)(cnt + tmp[len - 1 - i]);
-            T[p++] = (u16)c;
+            for (u64 i = 0; i < len; ++i) T[p++] = cnt + tmp[len - 1 - i];
+            T[p++] = c;
         }
         start[cnt] = p;
     }
@@ -191,8 +192,11 @@ inline BuiltBin buildBin(const std::vector<FastaRecord> & recs)
             if (!sentinelSuffix && off % 10 == 0)
             {
                 bitsWord |= 1u << (31 - t);
-                u8 recBytes[5]; recBytes[0] = (u8)c; memcpy(recBytes + 1, &off, 4);
-                B.val.insert(B.val.end(), recBytes, recBytes + 5);
+                // Pair<contig id, u32 offset>, packed: the id type follows the bin's own contig count (reference src/d_indexer.cpp:366-383)
+                u8 recBytes[6]; const size_t idBytes = cnt <= 255 ? 1 : 2;
+                recBytes[0] = (u8)c; if (idBytes == 2) recBytes[1] = (u8)(c >> 8);
+                memcpy(recBytes + idBytes, &off, 4);
+                B.val.insert(B.val.end(), recBytes, recBytes + idBytes + 4);
                 ++before;
             }
         }
@@ -231,7 +235,21 @@ inline void saveBin(const BuiltBin & B, const std::string & prefix)
     writeAll(prefix + ".lf.pst", B.pst, 20);
     writeAll(prefix + ".lf.drv", B.drv.data(), B.drv.size());
     writeAll(prefix + ".lf.drs", &B.drs, 1);
-    writeAll(prefix + ".lf.drp", B.drp.data(), B.drp.size() * 4);
+    if (B.count <= 255) writeAll(prefix + ".lf.drp", B.drp.data(), B.drp.size() * 4);         // Naive dictionary: the sentinel rows
+    else
+    {   // Levels bool dictionary over the rows, laid out like sa.ind (see host_formats.hpp appendBin)
+        const size_t nind = ((size_t)B.n + 31) / 32;
+        std::vector<u8> lv(nind * 8, 0);
+        std::vector<u32> bitsOf(nind, 0);
+        for (u32 r : B.drp) bitsOf[r >> 5] |= 1u << (31 - (r & 31));
+        u32 seen = 0;
+        for (size_t e = 0; e < nind; ++e)
+        {
+            memcpy(lv.data() + e * 8, &bitsOf[e], 4); memcpy(lv.data() + e * 8 + 4, &seen, 4);
+            seen += (u32)__builtin_popcount(bitsOf[e]);
+        }
+        writeAll(prefix + ".lf.drp", lv.data(), lv.size());
+    }
 }
 
 } // namespace dy

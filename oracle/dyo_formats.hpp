@@ -165,7 +165,7 @@ struct FMIndex
     u8 drs = 0;                      // sentinel substitute symbol
     std::vector<u32> drp;            // BWT rows holding a sentinel (ascending)
     std::vector<IndEntry> ind;
-    std::vector<u8>  valContig;      // unpacked SA samples
+    std::vector<u16> valContig;      // unpacked SA samples (u8 on disk for bins of up to 255 contigs, u16 above)
     std::vector<u32> valOffset;
     unsigned contigIdBytes = 1;      // 1 (u8 contigs) or 2 (u16 contigs), src/misc_types.h:184-188
 
@@ -241,19 +241,42 @@ inline FMIndex loadFMIndex(const std::string & prefix, u64 contigCount)
     }
     b = readFileBytes(prefix + ".lf.drs"); if (b.size() != 1) throw std::runtime_error("bad lf.drs"); fm.drs = b[0];
     b = readFileBytes(prefix + ".lf.drp");
-    if (contigCount > 255) throw std::runtime_error("bins with >255 contigs (Levels sentinel dictionary) are not supported");
-    fm.drp.resize(b.size() / 4); memcpy(fm.drp.data(), b.data(), fm.drp.size() * 4);
+    // The indexer picks the contig-id type from the bin's OWN contig count (reference src/d_indexer.cpp:366-383): up to 255 contigs ->
+    // uint8_t ids, sentinel rows as a plain position list (Naive dictionary, src/misc_types.h:165-167); up to 65535 -> uint16_t ids and
+    // a Levels bool dictionary over the n rows — the very type of sa.ind (RankDictionary<bool, Levels<void, YaraFMConfig>>), hence the
+    // same layout: 8 bytes per 32 rows, [u32 bits, row j at bit 31-j][u32 set bits before].  More than 65535 contigs per bin need the
+    // reference's DR_YARA_LARGE_CONTIGS build.  PARITY UNPINNED: the gold bins hold one contig each.
+    if (contigCount > 65535) throw std::runtime_error("Maximum number of contigs exceeded. Recompile with -DDR_YARA_LARGE_CONTIGS=ON.");
+    if (contigCount <= 255)
+    {
+        if (b.size() != contigCount * 4) throw std::runtime_error("unexpected lf.drp size");
+        fm.drp.resize(b.size() / 4); memcpy(fm.drp.data(), b.data(), fm.drp.size() * 4);
+    }
+    else
+    {
+        if (b.size() != ((size_t)fm.n + 31) / 32 * 8) throw std::runtime_error("unexpected lf.drp size (Levels form)");
+        for (size_t e = 0; e * 8 < b.size(); ++e)
+        {
+            u32 bits; memcpy(&bits, b.data() + e * 8, 4);
+            for (unsigned t = 0; t < 32; ++t) if ((bits >> (31 - t)) & 1) fm.drp.push_back((u32)(e * 32 + t));
+        }
+        if (fm.drp.size() != contigCount) throw std::runtime_error("lf.drp does not hold one sentinel per contig");
+    }
     b = readFileBytes(prefix + ".sa.ind");
     fm.ind.resize(b.size() / 8); memcpy(fm.ind.data(), b.data(), fm.ind.size() * 8);
     b = readFileBytes(prefix + ".sa.val");
-    fm.contigIdBytes = 1;
-    size_t rec = 5;
+    // sa.val: packed Pair<TContigsSize, uint32_t> (src/misc_types.h:184-188): 5 bytes with u8 ids, 6 bytes with u16 ids
+    fm.contigIdBytes = contigCount <= 255 ? 1 : 2;
+    const size_t rec = fm.contigIdBytes + 4;
+    if (b.size() % rec) throw std::runtime_error("unexpected sa.val record size");
     size_t cnt = b.size() / rec;
     fm.valContig.resize(cnt); fm.valOffset.resize(cnt);
     for (size_t i = 0; i < cnt; ++i)
     {
-        fm.valContig[i] = b[i * rec];
-        memcpy(&fm.valOffset[i], b.data() + i * rec + 1, 4);
+        u16 c = b[i * rec];
+        if (fm.contigIdBytes == 2) c |= (u16)b[i * rec + 1] << 8;
+        fm.valContig[i] = c;
+        memcpy(&fm.valOffset[i], b.data() + i * rec + fm.contigIdBytes, 4);
     }
     return fm;
 }

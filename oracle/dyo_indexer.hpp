@@ -105,6 +105,7 @@ struct BinIndexFiles
     Contigs contigs;
     FMIndex fm;
     std::vector<u8> saValFile;     // packed (contig, offset) records
+    std::vector<u8> drpFile;       // lf.drp: position list (<= 255 contigs) or Levels bool dictionary (see loadFMIndex)
 };
 
 inline BinIndexFiles buildBinIndex(const std::vector<std::string> & names, const std::vector<std::vector<u8> > & seqs)
@@ -112,7 +113,7 @@ inline BinIndexFiles buildBinIndex(const std::vector<std::string> & names, const
     BinIndexFiles out;
     Contigs & C = out.contigs;
     C.count = seqs.size();
-    if (C.count > 255) throw std::runtime_error("bins with >255 contigs are not supported");
+    if (C.count > 65535) throw std::runtime_error("Maximum number of contigs exceeded. Recompile with -DDR_YARA_LARGE_CONTIGS=ON.");   // reference src/d_indexer.cpp:376-382
     C.limits.assign(1, 0);
     for (size_t i = 0; i < seqs.size(); ++i)
     {
@@ -215,17 +216,39 @@ inline BinIndexFiles buildBinIndex(const std::vector<std::string> & names, const
             if (!sentinelSuffix && rowOffset[r] % 10 == 0)
             {
                 fm.ind[e].bits |= 1u << (31 - t);
-                fm.valContig.push_back((u8)rowContig[r]);
+                fm.valContig.push_back((u16)rowContig[r]);
                 fm.valOffset.push_back(rowOffset[r]);
                 ++before;
             }
         }
     }
-    out.saValFile.resize(fm.valOffset.size() * 5);
+    // the contig-id type follows the bin's own contig count (reference src/d_indexer.cpp:366-383)
+    fm.contigIdBytes = cnt <= 255 ? 1 : 2;
+    const size_t rec = fm.contigIdBytes + 4;
+    out.saValFile.resize(fm.valOffset.size() * rec);
     for (size_t i = 0; i < fm.valOffset.size(); ++i)
     {
-        out.saValFile[i * 5] = fm.valContig[i];
-        memcpy(out.saValFile.data() + i * 5 + 1, &fm.valOffset[i], 4);
+        out.saValFile[i * rec] = (u8)fm.valContig[i];
+        if (fm.contigIdBytes == 2) out.saValFile[i * rec + 1] = (u8)(fm.valContig[i] >> 8);
+        memcpy(out.saValFile.data() + i * rec + fm.contigIdBytes, &fm.valOffset[i], 4);
+    }
+    if (cnt <= 255)
+    {
+        out.drpFile.resize(fm.drp.size() * 4);
+        memcpy(out.drpFile.data(), fm.drp.data(), out.drpFile.size());
+    }
+    else
+    {   // Levels bool dictionary over the rows, laid out like sa.ind
+        out.drpFile.assign(nind * 8, 0);
+        u32 seen = 0;
+        for (size_t e = 0; e < nind; ++e)
+        {
+            u32 bits = 0;
+            for (unsigned t = 0; t < 32 && e * 32 + t < (size_t)n; ++t) if (isSent[e * 32 + t]) bits |= 1u << (31 - t);
+            memcpy(out.drpFile.data() + e * 8, &bits, 4);
+            memcpy(out.drpFile.data() + e * 8 + 4, &seen, 4);
+            seen += (u32)__builtin_popcount(bits);
+        }
     }
     return out;
 }
@@ -240,7 +263,7 @@ inline void saveBinIndex(const BinIndexFiles & b, const std::string & prefix)
     writeFileBytes(prefix + ".lf.pst", fm.pst, 20);
     writeFileBytes(prefix + ".lf.drv", fm.drv.data(), fm.drv.size() * 32);
     writeFileBytes(prefix + ".lf.drs", &fm.drs, 1);
-    writeFileBytes(prefix + ".lf.drp", fm.drp.data(), fm.drp.size() * 4);
+    writeFileBytes(prefix + ".lf.drp", b.drpFile.data(), b.drpFile.size());
 }
 
 // ----------------------------------------------------------------------------

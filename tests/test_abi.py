@@ -87,3 +87,35 @@ def test_product_indexer_matches_oracle_on_multi_contig_bin(product_build, oracl
     ob.build_bin_index(str(b / "0"), np.concatenate(contigs), offs)
     for n in sorted(os.listdir(a)):
         assert filecmp.cmp(str(a / n), str(b / n), shallow=False), n
+
+
+@pytest.mark.parametrize("n_contigs", [255, 256, 300, 3000])
+def test_indexers_agree_across_the_contig_id_width_boundary(product_build, oracle_build, tmp_path, n_contigs):
+    """Up to 255 contigs a bin is indexed with u8 contig ids (5-byte sa.val records, lf.drp = list of sentinel rows); from 256 on with
+    u16 ids (6-byte records) and lf.drp as a Levels bool dictionary over the rows (reference src/d_indexer.cpp:366-383,
+    src/misc_types.h:165-188).  Product indexer and oracle agree on every file, and the file sizes follow the layout.
+    PARITY UNPINNED: every gold bin holds one contig, and SeqAn's serialisation of the Levels dictionary is inferred from sa.ind."""
+    import oracle_binding as ob
+    rng = np.random.default_rng(n_contigs)
+    contigs = [rng.integers(0, 4, int(rng.integers(40, 200)), dtype=np.uint8) for _ in range(n_contigs)]
+    contigs[1][:30] = contigs[0][:30]; contigs[2][5] = 4
+    fa = tmp_path / "0.fna"
+    with open(fa, "wb") as f:
+        for i, c in enumerate(contigs):
+            f.write(b">c%d\n" % i + np.frombuffer(b"ACGTN", np.uint8)[c].tobytes() + b"\n")
+    a = tmp_path / "a"; a.mkdir()
+    b = tmp_path / "b"; b.mkdir()
+    subprocess.check_call([os.path.join(product_build, "dream_yara_indexer"), "-o", str(a) + "/", str(fa)])
+    offs = np.zeros(n_contigs + 1, np.uint64); offs[1:] = np.cumsum([c.size for c in contigs])
+    ob.build_bin_index(str(b / "0"), np.concatenate(contigs), offs)
+    for n in sorted(os.listdir(a)):
+        if n.startswith("0.rid"):
+            continue                                    # the oracle binding names contigs contig<i>
+        assert filecmp.cmp(str(a / n), str(b / n), shallow=False), n
+    rows = int(offs[-1]) + n_contigs
+    samples = os.path.getsize(a / "0.sa.val") // (5 if n_contigs <= 255 else 6)
+    assert os.path.getsize(a / "0.sa.val") == samples * (5 if n_contigs <= 255 else 6)
+    assert os.path.getsize(a / "0.lf.drp") == (n_contigs * 4 if n_contigs <= 255 else (rows + 31) // 32 * 8)
+    # and the oracle loads what was written
+    oidx = ob.OracleIndex(str(a) + "/", 1)
+    oidx.close()

@@ -994,6 +994,48 @@ def test_multi_contig_bins_match_oracle(dy, ctx, ob, tmp_path, use_filter):
     if oibf: oibf.close()
 
 
+@pytest.mark.parametrize("n_contigs,contig_len", [(300, 900), (40000, 130)])
+def test_bins_with_more_than_255_contigs_match_oracle(dy, ctx, ob, tmp_path, n_contigs, contig_len):
+    """Draft-assembly-like bins: hundreds to tens of thousands of contigs per bin -> u16 contig ids in sa.val and the Levels form of
+    lf.drp (reference src/misc_types.h:165-188, src/d_indexer.cpp:366-383); a second, single-contig bin shares a repeat with the first.
+    Device == oracle on every field, global contig ids beyond 65535 included.  PARITY UNPINNED (no multi-contig gold bin exists)."""
+    rng = np.random.default_rng(n_contigs)
+    big = [rng.integers(0, 4, contig_len + int(rng.integers(0, 40)), dtype=np.uint8) for _ in range(n_contigs)]
+    big[7][:100] = big[3][:100]; big[11][20:23] = 4
+    other = [rng.integers(0, 4, 30000, dtype=np.uint8)]
+    other[0][1000:1120] = big[5][:120]
+    bins = [other, big, [rng.integers(0, 4, 500, dtype=np.uint8) for _ in range(30000)]] if n_contigs > 30000 else [other, big]
+    n_bins = len(bins)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, cs in enumerate(bins):
+        offs = np.zeros(len(cs) + 1, np.uint64); offs[1:] = np.cumsum([c.size for c in cs])
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), np.concatenate(cs), offs)
+    whole = [np.concatenate(cs) for cs in bins]
+    fpath = str(tmp_path / "f.filter")
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in whole])
+    ob.build_filter(fpath, n_bins, 3, 16, 1 << 27, np.concatenate(whole), goffs)
+    reads = []
+    for i in range(3000):
+        cs = bins[int(rng.integers(0, n_bins))]
+        c = cs[int(rng.integers(0, len(cs)))]
+        L = 100
+        s = int(rng.integers(0, c.size - L)); r = c[s:s + L].copy()
+        for _ in range(int(rng.integers(0, 4))): r[int(rng.integers(0, L))] = rng.integers(0, 4)
+        if i % 2: r = np.where(r[::-1] < 4, 3 - r[::-1], 4).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads); offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    er = np.float32(0.03)
+    dev, stats = device_map(dy, ctx, idx_dir, n_bins, fpath, codes, offs, er, np.float32(0.02))
+    oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath)
+    o = ob.map_batch(oidx, oibf, codes, offs, er, np.float32(0.02), threads=8)
+    oidx.close(); oibf.close()
+    assert stats["items"] == o[3]["items"] and stats["raw_matches"] == o[3]["raw_matches"]
+    assert_results_equal(dev, o[:3])
+    mapped = dev[0]["mapped"] == 1
+    assert mapped.sum() > 2500
+    assert dev[0]["primary"]["contig"][mapped].max() > (65535 if n_contigs > 30000 else 255)        # ids beyond the narrower type are reported
+
+
 # ---------------------------------------------------------------------------------------------- error behaviour of the boundary
 def test_abi_error_codes_and_messages(dy, ctx, small_filter, tmp_path):
     """Errors come back as DY_E* codes with the reference's wording where it has one (reference src/mapper.h:453-454,
