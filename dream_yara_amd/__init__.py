@@ -87,6 +87,7 @@ SYMBOLS = [
     ("dy_reads_count", C.c_uint32, [_P]),
     ("dy_reads_free", None, [_P]),
     ("dy_ibf_query", C.c_int, [_P, _P, C.c_uint16, _P]),
+    ("dy_reads_select_all_bins", C.c_int, [_P, _P, C.c_uint32]),
     ("dy_index_load", C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(_P)]),
     ("dy_index_bins", C.c_uint32, [_P]),
     ("dy_index_contigs", C.c_uint32, [_P]),

@@ -56,7 +56,9 @@ def build(force=False):
         if force or not _newer(exe, [src, LIB] + [s for s in srcs if s.endswith((".h", ".hpp"))]):
             link = [] if tool == "dream_yara_indexer" else ["-L" + CSRC, "-ldyhip", "-Wl,-rpath,$ORIGIN"]
             if tool == "dream_yara_mapper":
-                link = ["-DDY_HAVE_ZLIB"] + link + ["-lz"]          # BAM output, gzip input
+                # BAM output, gzip input; the HIP runtime API for the device buffers of the multi-GPU exchange (multi_gpu.hpp; RCCL itself is
+                # loaded on demand).  -D__HIP_PLATFORM_AMD__ only tells the runtime header which of its two API sets to declare.
+                link = ["-DDY_HAVE_ZLIB", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + link + ["-lz", "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
             _run(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, src] + link)
     return LIB
 

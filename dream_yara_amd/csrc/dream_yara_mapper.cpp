@@ -4,6 +4,7 @@
 #include "../../include/dyhip.h"
 #include "host_formats.hpp"
 #include "bam_writer.hpp"
+#include "multi_gpu.hpp"
 #include <charconv>
 #include <iostream>
 #include <fstream>
@@ -13,6 +14,7 @@
 #include <memory>
 #include <thread>
 #include <future>
+#include <atomic>
 
 using namespace dy;
 
@@ -26,6 +28,11 @@ struct CliOptions
     unsigned hostThreads = 0;          // 0 = min(16, hardware threads)
     bool verbose = false, skipSamHeader = false;
     std::string commandLine;
+    // ---- not in the reference (its -t threads share one address space): devices of this node
+    unsigned gpus = 1;                  // --gpus N
+    std::vector<int> devices;           // --devices 0,1,...  (default 0..N-1; a device may be listed twice: two contexts on it, used by the tests)
+    std::string shard = "reads";        // --shard reads | bins   (multi_gpu.hpp)
+    std::string transport = "auto";     // --transport auto | rccl | copy   (bins mode)
 };
 
 [[noreturn]] void fail(const std::string & msg) { throw std::runtime_error(msg); }
@@ -72,6 +79,14 @@ CliOptions parse(int argc, char ** argv)
         else if (a == "-i" || a == "--indel-rate") o.params.indel_rate = (float)(uintValue(0, 50) / 100.0);         // :355-357
         else if (a == "-ni" || a == "--no-indels") o.params.verify_matches = 0;                                      // :359
         else if (a == "-v" || a == "--verbose" || a == "-vv" || a == "--very-verbose") o.verbose = true;
+        else if (a == "--gpus") o.gpus = uintValue(1, 64);
+        else if (a == "--devices")
+        {
+            std::stringstream ss(value()); std::string tok;
+            while (std::getline(ss, tok, ',')) { try { o.devices.push_back(std::stoi(tok)); } catch (...) { fail("--devices takes a comma-separated list of device ordinals"); } }
+        }
+        else if (a == "--shard") { o.shard = value(); if (o.shard != "reads" && o.shard != "bins") fail("--shard takes reads or bins"); }
+        else if (a == "--transport") { o.transport = value(); if (o.transport != "auto" && o.transport != "rccl" && o.transport != "copy") fail("--transport takes auto, rccl or copy"); }
         else if (a.size() > 1 && a[0] == '-') fail("unknown option " + a);
         else pos.push_back(a);
     }
@@ -82,6 +97,8 @@ CliOptions parse(int argc, char ** argv)
     if (o.indicesDir.empty() || o.indicesDir.back() != '/') o.indicesDir += '/';                                // appendTrailingSlash :280
     if (o.filterFile.empty()) o.filterFile = o.indicesDir + "bloom.filter";                                     // :371-375
     if (o.readsBatch > 2097151) o.readsBatch = 2097151;
+    if (!o.devices.empty()) o.gpus = (unsigned)o.devices.size();
+    else for (unsigned d = 0; d < o.gpus; ++d) o.devices.push_back((int)d);
     for (int i = 0; i < argc; ++i) { if (i) o.commandLine += ' '; o.commandLine += argv[i]; }
     return o;
 }
@@ -96,23 +113,73 @@ int main(int argc, char ** argv)
     {
         CliOptions opt = parse(argc, argv);
         auto t0 = std::chrono::steady_clock::now();
-        dy_ctx * ctx = nullptr; check(dy_ctx_create(0, &ctx));
-        dy_ibf * ibf = nullptr;
+        const unsigned N = opt.gpus;
+        // bins are sharded when there is something to shard over — or when a transport is named, which runs the whole exchange sequence
+        // on one device too (a self send/receive through RCCL: the only RCCL rehearsal a one-GPU box allows)
+        const bool shardBins = opt.shard == "bins" && (opt.gpus > 1 || opt.transport != "auto");
+        // one context (+ filter + index) per listed device
+        struct Device { int ordinal = 0; dy_ctx * ctx = nullptr; dy_ibf * ibf = nullptr; dy_index * idx = nullptr; };
+        std::vector<Device> devs(N);
         uint32_t nBins = 0;
-        if (opt.filterType == "bloom" || opt.filterType == "kmer_direct")
-        {   // reference src/d_mapper.h:910-936
-            check(opt.filterType == "bloom" ? dy_ibf_load(ctx, opt.filterFile.c_str(), &ibf) : dy_kdx_load(ctx, opt.filterFile.c_str(), &ibf));
-            dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
-            nBins = info.n_bins;                                                                                // readFilterMetadata :532-548
-        }
-        else
+        if (!(opt.filterType == "bloom" || opt.filterType == "kmer_direct"))
         {
             opt.params.use_filter = 0;
             for (;; ++nBins) { std::ifstream f(opt.indicesDir + std::to_string(nBins) + ".txt.size"); if (!f) break; }
             if (!nBins) fail("Error while opening reference file.");
         }
-        dy_index * idx = nullptr; check(dy_index_load(ctx, opt.indicesDir.c_str(), nBins, &idx));
+        {
+            std::vector<std::string> errors(N);
+            auto setup = [&](unsigned d) {
+                try
+                {
+                    Device & D = devs[d];
+                    D.ordinal = opt.devices[d];
+                    check(dy_ctx_create(D.ordinal, &D.ctx));
+                    uint32_t bins = nBins;
+                    if (opt.params.use_filter)
+                    {   // reference src/d_mapper.h:910-936
+                        check(opt.filterType == "bloom" ? dy_ibf_load(D.ctx, opt.filterFile.c_str(), &D.ibf) : dy_kdx_load(D.ctx, opt.filterFile.c_str(), &D.ibf));
+                        dy_ibf_info info; check(dy_ibf_get_info(D.ibf, &info));
+                        bins = info.n_bins;                                                                         // readFilterMetadata :532-548
+                    }
+                    if (shardBins)
+                    {
+                        std::vector<uint8_t> owned(bins);
+                        for (uint32_t b = 0; b < bins; ++b) owned[b] = b % N == d;
+                        check(dy_index_load_sharded(D.ctx, opt.indicesDir.c_str(), bins, owned.data(), &D.idx));
+                    }
+                    else check(dy_index_load(D.ctx, opt.indicesDir.c_str(), bins, &D.idx));
+                }
+                catch (std::exception const & e) { errors[d] = e.what(); }
+            };
+            std::vector<std::thread> th;
+            for (unsigned d = 1; d < N; ++d) th.emplace_back(setup, d);
+            setup(0);
+            for (auto & t : th) t.join();
+            for (auto & e : errors) if (!e.empty()) fail(e);
+            nBins = dy_index_bins(devs[0].idx);
+        }
+        dy_index * idx = devs[0].idx;
         auto t1 = std::chrono::steady_clock::now();
+        // bins mode: one ShardRank per device + the exchange between them
+        std::unique_ptr<Exchange> exchange;
+        std::vector<ShardRank> ranks;
+        if (shardBins)
+        {
+            bool distinct = true;
+            for (unsigned i = 0; i < N; ++i) for (unsigned j = 0; j < i; ++j) distinct &= opt.devices[i] != opt.devices[j];
+            if (opt.transport == "rccl" && !distinct) fail("--transport rccl needs distinct devices");
+            exchange.reset(new Exchange(opt.devices, opt.transport == "rccl" || (opt.transport == "auto" && distinct)));
+            ranks.resize(N);
+            const uint32_t W = (nBins + 63) / 64;
+            for (unsigned d = 0; d < N; ++d)
+            {
+                ShardRank & R = ranks[d];
+                R.rank = d; R.nRanks = N; R.device = devs[d].ordinal; R.ctx = devs[d].ctx; R.ibf = devs[d].ibf; R.idx = devs[d].idx; R.nBins = nBins; R.W = W;
+                R.ownerMasks.assign((size_t)N * W, 0);
+                for (uint32_t b = 0; b < nBins; ++b) R.ownerMasks[(size_t)(b % N) * W + b / 64] |= 1ull << (b % 64);
+            }
+        }
 
         // output format by extension (reference src/d_mapper.cpp:140-153): .bam -> BGZF-compressed BAM, anything else -> SAM text
         const bool bam = opt.outputFile.size() >= 4 && opt.outputFile.compare(opt.outputFile.size() - 4, 4, ".bam") == 0;
@@ -138,16 +205,22 @@ int main(int argc, char ** argv)
         std::unique_ptr<ReadsFile> in2;
         if (opt.params.paired) in2.reset(new ReadsFile(opt.readsFile2));
         if (opt.params.paired && opt.readsBatch > 1048575) opt.readsBatch = 1048575;      // both mates share the 21-bit read id space
-        // Three batches are in flight: one being parsed, one on the device, one being formatted and written (in input order).
-        struct Slot { ReadsBatch batch; dy_reads * reads = nullptr; dy_result * res = nullptr; size_t nPairs = 0; };
-        Slot slots[3];
+        // A batch is mapped in PARTS: one part = the whole batch on one device (--shard reads: consecutive batches go to consecutive
+        // devices) or, with --shard bins, the slice of the batch that is at home on a device.  A part covers reads [lo, hi) (single-end)
+        // or pairs [lo, hi) = reads [lo, hi) + [P + lo, P + hi) (paired).  Three ROUNDS of up to N batches are in flight: one being
+        // parsed, one on the devices, one being formatted and written (in input order).
+        struct Part { size_t lo = 0, hi = 0; unsigned dev = 0; dy_reads * reads = nullptr; dy_result * res = nullptr; std::vector<u8> codes; std::vector<u64> offs; };
+        struct Slot { ReadsBatch batch; size_t nPairs = 0; std::vector<Part> parts; };
+        struct Round { std::vector<Slot> slots; size_t used = 0; };
+        const unsigned perRound = shardBins ? 1u : N;
+        Round rounds[3];
+        for (auto & r : rounds) r.slots.resize(perRound);
         unsigned long long total = 0, mapped = 0;
         double mapSeconds = 0, parseSeconds = 0, formatSeconds = 0, writeSeconds = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
         auto readInto = [&](Slot & sl) -> bool {
             ReadsBatch & batch = sl.batch;
-            const auto p0 = now();
             if (!in.next(batch, opt.readsBatch, hostThreads)) return false;
             if (in2)
             {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
@@ -160,26 +233,39 @@ int main(int argc, char ** argv)
                 for (size_t i = 1; i < second.offs.size(); ++i) batch.offs.push_back(second.offs[i] + shift);
             }
             sl.nPairs = batch.size() / 2;
-            parseSeconds += since(p0);
             return true;
         };
-        auto formatAndWrite = [&](Slot & sl) {
+        auto readRound = [&](Round & rd) -> bool {
+            const auto p0 = now();
+            rd.used = 0;
+            while (rd.used < rd.slots.size() && readInto(rd.slots[rd.used])) ++rd.used;
+            parseSeconds += since(p0);
+            return rd.used > 0;
+        };
+        // batch index of part-local read j
+        auto batchIndex = [&](const Slot & sl, const Part & pt, size_t j) -> size_t {
+            if (!opt.params.paired) return pt.lo + j;
+            const size_t np = pt.hi - pt.lo;
+            return j < np ? pt.lo + j : sl.nPairs + pt.lo + (j - np);
+        };
+        // ---- alignment records of part-local reads [jlo, jhi) (reference src/mapper_writer.h:296-345, 593-634; pairs :268-293,347-400,515-571)
+        auto formatRange = [&](const Slot & sl, const Part & pt, size_t jlo, size_t jhi, std::string & sam, std::vector<uint8_t> & bamOut, unsigned long long & nMapped) {
             const ReadsBatch & batch = sl.batch;
-            const size_t nPairs = sl.nPairs;
-            const dy_read_result * rr = dy_result_reads(sl.res);
-            const dy_match * ms = dy_result_matches(sl.res);
-            const uint32_t * cg = dy_result_cigars(sl.res);
-            // ---- alignment records (reference src/mapper_writer.h:296-345, 593-634; pairs :268-293,347-400,515-571)
-            const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(hostThreads, batch.size() / 4096 + 1));
-            std::vector<std::string> samChunk(T); std::vector<std::vector<uint8_t>> bamChunk(T); std::vector<unsigned long long> mappedChunk(T, 0);
-            auto formatChunk = [&](unsigned c) {
-            const size_t lo = batch.size() * c / T, hi = batch.size() * (c + 1) / T;
-            if (bam && hi > lo) bamChunk[c].reserve((hi - lo) * (size_t)(2 * (batch.offs[lo + 1] - batch.offs[lo]) + 96));
-            if (!bam && hi > lo) samChunk[c].reserve((hi - lo) * (size_t)(2 * (batch.offs[lo + 1] - batch.offs[lo]) + 96));
-            AlnRecord a;                    // reused: its strings keep their capacity
-            for (size_t i = lo; i < hi; ++i)
+            const size_t np = opt.params.paired ? pt.hi - pt.lo : 0;
+            const dy_read_result * rr = dy_result_reads(pt.res);
+            const dy_match * ms = dy_result_matches(pt.res);
+            const uint32_t * cg = dy_result_cigars(pt.res);
+            if (jhi > jlo)
             {
-                const dy_read_result & r = rr[i];
+                const size_t i0 = batchIndex(sl, pt, jlo);
+                const size_t guess = (jhi - jlo) * (size_t)(2 * (batch.offs[i0 + 1] - batch.offs[i0]) + 96);
+                if (bam) bamOut.reserve(guess); else sam.reserve(guess);
+            }
+            AlnRecord a;                    // reused: its strings keep their capacity
+            for (size_t j = jlo; j < jhi; ++j)
+            {
+                const size_t i = batchIndex(sl, pt, j);
+                const dy_read_result & r = rr[j];
                 a.flag = 0; a.rid = a.pos = -1; a.mapq = 0; a.cigar = nullptr; a.nCigar = 0; a.rnext = a.pnext = -1; a.tlen = 0;
                 a.hasCounts = false; a.nm = a.x0 = a.x1 = 0; a.xa.clear();
                 const std::string & name = batch.names[i];
@@ -198,8 +284,8 @@ int main(int argc, char ** argv)
                 else a.flag |= 4;
                 if (opt.params.paired)
                 {
-                    const dy_read_result & mr = rr[i < nPairs ? i + nPairs : i - nPairs];
-                    a.flag |= 1u | (i < nPairs ? 64u : 128u);
+                    const dy_read_result & mr = rr[j < np ? j + np : j - np];
+                    a.flag |= 1u | (j < np ? 64u : 128u);
                     if (!mr.mapped) a.flag |= 8;
                     if (mr.mapped && mr.primary.is_rev) a.flag |= 32;
                     if (r.mapped && mr.mapped && r.paired)
@@ -234,79 +320,162 @@ int main(int argc, char ** argv)
                         appendUint(a.xa, m.errors); a.xa += ';';
                     }
                 }
-                if (bam) bamEncodeRecord(a, bamChunk[c]);
-                else samWriteRecord(samChunk[c], a, contigNames);
-                mappedChunk[c] += r.mapped;
+                if (bam) bamEncodeRecord(a, bamOut);
+                else samWriteRecord(sam, a, contigNames);
+                nMapped += r.mapped;
             }
-            };
+        };
+        auto formatAndWrite = [&](Slot & sl) {
+            // output order = input order: the first mates of every part, then the second mates of every part (single-end: one pass)
+            struct Chunk { const Part * pt; size_t jlo, jhi; std::string sam; std::vector<uint8_t> bam; unsigned long long nMapped = 0; };
+            std::vector<Chunk> chunks;
+            const unsigned passes = opt.params.paired ? 2 : 1;
+            for (unsigned pass = 0; pass < passes; ++pass)
+                for (const Part & pt : sl.parts)
+                {
+                    const size_t np = pt.hi - pt.lo;
+                    const size_t base = pass * np;
+                    const size_t pieces = std::max<size_t>(1, std::min<size_t>(hostThreads, np / 4096 + 1));
+                    for (size_t c = 0; c < pieces; ++c) { Chunk ch; ch.pt = &pt; ch.jlo = base + np * c / pieces; ch.jhi = base + np * (c + 1) / pieces; chunks.push_back(std::move(ch)); }
+                }
             const auto f0 = now();
             {
+                std::atomic<size_t> next(0);
+                auto work = [&] { for (;;) { const size_t c = next.fetch_add(1); if (c >= chunks.size()) break; Chunk & ch = chunks[c]; formatRange(sl, *ch.pt, ch.jlo, ch.jhi, ch.sam, ch.bam, ch.nMapped); } };
+                const unsigned T = (unsigned)std::min<size_t>(hostThreads, chunks.size());
                 std::vector<std::thread> pool;
-                for (unsigned c = 1; c < T; ++c) pool.emplace_back(formatChunk, c);
-                formatChunk(0);
+                for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
+                work();
                 for (auto & th : pool) th.join();
             }
             formatSeconds += since(f0);
             const auto w0 = now();
-            for (unsigned c = 0; c < T; ++c)
+            for (Chunk & ch : chunks)
             {
-                if (bam) bgzf.writeParallel(bamChunk[c].data(), bamChunk[c].size(), hostThreads);
-                else os.write(samChunk[c].data(), (std::streamsize)samChunk[c].size());
-                mapped += mappedChunk[c];
+                if (bam) bgzf.writeParallel(ch.bam.data(), ch.bam.size(), hostThreads);
+                else os.write(ch.sam.data(), (std::streamsize)ch.sam.size());
+                mapped += ch.nMapped;
             }
-            total += batch.size();
+            total += sl.batch.size();
             writeSeconds += since(w0);
         };
-        auto release = [&](Slot & sl) {          // device objects go back on the thread that drives the context
-            if (sl.res) { dy_result_free(sl.res); sl.res = nullptr; }
-            if (sl.reads) { dy_reads_free(sl.reads); sl.reads = nullptr; }
+        auto writeRound = [&](Round & rd) { for (size_t i = 0; i < rd.used; ++i) formatAndWrite(rd.slots[i]); };
+        auto releaseRound = [&](Round & rd) {          // device objects go back while no thread drives the contexts
+            for (size_t i = 0; i < rd.used; ++i)
+                for (Part & pt : rd.slots[i].parts)
+                {
+                    if (pt.res) { dy_result_free(pt.res); pt.res = nullptr; }
+                    if (pt.reads) { dy_reads_free(pt.reads); pt.reads = nullptr; }
+                }
+        };
+        auto thresholdOf = [&](const ReadsBatch & batch, dy_ibf * ibf) -> uint16_t {
+            // threshold from the batch-average read length (reference src/d_mapper.h:313-315)
+            uint16_t avg = (uint16_t)(batch.offs.back() * 2 / (batch.size() * 2));
+            dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
+            uint16_t thr = dy_ibf_threshold(opt.params.error_rate, info.kmer_size, avg);
+            if (thr == 0) std::cerr << "[WARNING!] 0 k-mer is required to filter a read!\nAll reads will pass filteration and be mapped everywhere.\n";
+            return thr;
+        };
+        // one whole batch on one device (single GPU, and --shard reads)
+        auto mapWhole = [&](Slot & sl, unsigned d) {
+            Device & D = devs[d];
+            sl.parts.assign(1, Part());
+            Part & pt = sl.parts[0];
+            pt.dev = d; pt.lo = 0; pt.hi = opt.params.paired ? sl.nPairs : sl.batch.size();
+            const ReadsBatch & batch = sl.batch;
+            check(dy_reads_upload(D.ctx, batch.codes.data(), batch.offs.data(), (uint32_t)batch.size(), &pt.reads));
+            if (D.ibf) check(dy_ibf_query(D.ibf, pt.reads, thresholdOf(batch, D.ibf), nullptr));
+            check(dy_map_reads(D.ctx, D.idx, pt.reads, &opt.params, &pt.res));
+        };
+        // one batch over all devices, bins sharded: device d is home to the d-th slice of the reads (pairs)
+        auto mapSharded = [&](Slot & sl) {
+            const ReadsBatch & batch = sl.batch;
+            const size_t units = opt.params.paired ? sl.nPairs : batch.size();
+            const uint16_t thr = devs[0].ibf ? thresholdOf(batch, devs[0].ibf) : 0;
+            sl.parts.assign(N, Part());
+            std::vector<std::string> errors(N);
+            auto rankWork = [&](unsigned d) {
+                try
+                {
+                    Part & pt = sl.parts[d];
+                    pt.dev = d; pt.lo = units * d / N; pt.hi = units * (d + 1) / N;
+                    // the slice as its own batch: reads [lo, hi) (+ their mates behind them)
+                    pt.codes.clear(); pt.offs.assign(1, 0);
+                    const unsigned halves = opt.params.paired ? 2 : 1;
+                    for (unsigned h = 0; h < halves; ++h)
+                        for (size_t u = pt.lo; u < pt.hi; ++u)
+                        {
+                            const size_t i = h * sl.nPairs + u;
+                            pt.codes.insert(pt.codes.end(), batch.codes.begin() + batch.offs[i], batch.codes.begin() + batch.offs[i + 1]);
+                            pt.offs.push_back(pt.codes.size());
+                        }
+                    Device & D = devs[d];
+                    check(dy_reads_upload(D.ctx, pt.codes.data(), pt.offs.data(), (uint32_t)(pt.offs.size() - 1), &pt.reads));
+                    if (D.ibf) check(dy_ibf_query(D.ibf, pt.reads, thr, nullptr));
+                    else check(dy_reads_select_all_bins(D.ctx, pt.reads, nBins));
+                    pt.res = ranks[d].mapBatch(*exchange, pt.reads, opt.params);
+                }
+                catch (std::exception const & e) { errors[d] = e.what(); exchange->abort(); }
+            };
+            std::vector<std::thread> th;
+            for (unsigned d = 1; d < N; ++d) th.emplace_back(rankWork, d);
+            rankWork(0);
+            for (auto & t : th) t.join();
+            for (auto & e : errors) if (!e.empty() && e != "another rank failed") fail(e);
+            for (auto & e : errors) if (!e.empty()) fail(e);
+        };
+        auto mapRound = [&](Round & rd) {
+            const auto m0 = now();
+            if (shardBins) mapSharded(rd.slots[0]);
+            else
+            {
+                std::vector<std::string> errors(rd.used);
+                auto work = [&](size_t i) { try { mapWhole(rd.slots[i], (unsigned)i); } catch (std::exception const & e) { errors[i] = e.what(); } };
+                std::vector<std::thread> th;
+                for (size_t i = 1; i < rd.used; ++i) th.emplace_back(work, i);
+                work(0);
+                for (auto & t : th) t.join();
+                for (auto & e : errors) if (!e.empty()) fail(e);
+            }
+            mapSeconds += since(m0);
         };
         std::future<void> writer;                // at most one: keeps the output in input order
         int writing = -1;
         int cur = 0;
-        bool have = readInto(slots[cur]);
+        bool have = readRound(rounds[cur]);
         while (have)
         {
-            Slot & sl = slots[cur];
             const int nxt = (cur + 1) % 3;
-            if (writing == nxt) { writer.get(); release(slots[nxt]); writing = -1; }      // the slot about to be refilled must be written out
-            std::future<bool> reader = std::async(std::launch::async, [&, nxt] { return readInto(slots[nxt]); });
-            const ReadsBatch & batch = sl.batch;
-            auto m0 = std::chrono::steady_clock::now();
-            check(dy_reads_upload(ctx, batch.codes.data(), batch.offs.data(), (uint32_t)batch.size(), &sl.reads));
-            if (ibf)
-            {
-                // threshold from the batch-average read length (reference src/d_mapper.h:313-315)
-                uint16_t avg = (uint16_t)(batch.offs.back() * 2 / (batch.size() * 2));
-                dy_ibf_info info; check(dy_ibf_get_info(ibf, &info));
-                uint16_t thr = dy_ibf_threshold(opt.params.error_rate, info.kmer_size, avg);
-                if (thr == 0) std::cerr << "[WARNING!] 0 k-mer is required to filter a read!\nAll reads will pass filteration and be mapped everywhere.\n";
-                check(dy_ibf_query(ibf, sl.reads, thr, nullptr));
-            }
-            check(dy_map_reads(ctx, idx, sl.reads, &opt.params, &sl.res));
-            mapSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - m0).count();
-            if (writing >= 0) { writer.get(); release(slots[writing]); writing = -1; }
-            writer = std::async(std::launch::async, [&, cur] { formatAndWrite(slots[cur]); });
+            if (writing == nxt) { writer.get(); releaseRound(rounds[nxt]); writing = -1; }      // the round about to be refilled must be written out
+            std::future<bool> reader = std::async(std::launch::async, [&, nxt] { return readRound(rounds[nxt]); });
+            mapRound(rounds[cur]);
+            if (writing >= 0) { writer.get(); releaseRound(rounds[writing]); writing = -1; }
+            writer = std::async(std::launch::async, [&, cur] { writeRound(rounds[cur]); });
             writing = cur;
             have = reader.get();
             cur = nxt;
         }
-        if (writing >= 0) { writer.get(); release(slots[writing]); }
+        if (writing >= 0) { writer.get(); releaseRound(rounds[writing]); }
         if (bam) bgzf.finish();
         os.flush();
         if (opt.verbose)
         {
-            dy_map_stats s; dy_map_get_stats(ctx, &s);
-            std::cerr << "Loading time:\t\t\t" << std::chrono::duration<double>(t1 - t0).count() << " sec\n"
+            dy_map_stats s; dy_map_get_stats(devs[0].ctx, &s);
+            std::cerr << "Devices:\t\t\t" << N << (N > 1 ? (shardBins ? (exchange->rccl() ? " (bins sharded, RCCL)" : " (bins sharded, device-to-device copies)") : " (reads sharded)") : "") << "\n"
+                      << "Loading time:\t\t\t" << std::chrono::duration<double>(t1 - t0).count() << " sec\n"
                       << "Mapping time:\t\t\t" << mapSeconds << " sec\n"
                       << "Parse / format / write time (overlapped with mapping):\t" << parseSeconds << " / " << formatSeconds << " / " << writeSeconds << " sec\n"
                       << "Total reads:\t\t\t" << total << "\nMapped reads:\t\t\t" << mapped << "\n"
-                      << "Last batch: items " << s.items << ", raw matches " << s.raw_matches << ", hard items " << s.hard_items
+                      << "Last batch (device 0): items " << s.items << ", raw matches " << s.raw_matches << ", hard items " << s.hard_items
                       << ", ms ibf/items/search/extend/finalize " << s.ms_ibf << "/" << s.ms_items << "/" << s.ms_search << "/" << s.ms_extend << "/" << s.ms_finalize << "\n";
         }
-        dy_index_free(idx);
-        if (ibf) dy_ibf_free(ibf);
-        dy_ctx_free(ctx);
+        ranks.clear(); exchange.reset();
+        for (auto & D : devs)
+        {
+            if (D.idx) dy_index_free(D.idx);
+            if (D.ibf) dy_ibf_free(D.ibf);
+            if (D.ctx) dy_ctx_free(D.ctx);
+        }
     }
     catch (std::exception const & e)
     {

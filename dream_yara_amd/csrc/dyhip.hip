@@ -1135,6 +1135,23 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
     });
 }
 
+int dy_reads_select_all_bins(dy_ctx * ctx, dy_reads * reads, uint32_t n_bins)
+{
+    return guarded([&] {
+        if (!ctx || !reads) throw DyError(DY_EINVAL, "dy_reads_select_all_bins: NULL argument");
+        if (reads->ctx != ctx) throw DyError(DY_EINVAL, "reads belong to a different context");
+        if (n_bins == 0 || n_bins > 65535) throw DyError(DY_EINVAL, "number of bins out of range");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        const u32 W = (n_bins + 63) / 64;
+        if (reads->recycle && !reads->masks.p) takeBuffer(ctx, reads->masks, (size_t)reads->n * W * 8 + 8);
+        else reads->masks.reserve((size_t)reads->n * W * 8 + 8);
+        reads->maskW = W; reads->maskBins = n_bins;
+        if (reads->n) hipLaunchKernelGGL(k_fill_masks, dim3((u32)(((u64)reads->n * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), reads->n, W, n_bins);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
 // ---- index --------------------------------------------------------------------------------------------
 static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint8_t * owned, dy_index ** out)
 {

@@ -111,6 +111,10 @@ void dy_reads_free(dy_reads *r);
  * threshold 0 reproduces the reference's "every read to every bin" (src/d_mapper.h:320-333) without the duplicate pass. */
 int  dy_ibf_query(dy_ibf *f, dy_reads *reads, uint16_t threshold, uint64_t *bin_masks_host);
 
+/* `-ft none`: every read goes to every bin (reference src/d_mapper.h:399-405) — sets the masks dy_ibf_query would set.  dy_map_reads does
+ * this by itself when use_filter = 0; the bins-sharded sequence (dy_shard_plan ...) needs the masks on the reads first. */
+int  dy_reads_select_all_bins(dy_ctx *ctx, dy_reads *reads, uint32_t n_bins);
+
 /* ---- index ------------------------------------------------------------------------------------------- */
 /* loadContigs + loadContigsIndex for every bin — reference src/mapper.h:362-403, src/index_fm.h:84-103,
  * src/store_seqs.h:128-141.  Reads <dir>/<b>.{txt.size,txt.limits,txt.concat,rid.limits,rid.concat,sa.len,sa.ind,

@@ -367,6 +367,21 @@ def test_cli_reproduces_gold_sam(product_build, dy, small_filter, tmp_path, gold
     assert [(a, b) for a, b in zip(mine, ref) if a != b] == []
 
 
+@pytest.mark.parametrize("extra", [["--devices", "0,0"], ["--devices", "0,0,0", "--shard", "bins"], ["--devices", "0", "--shard", "bins", "--transport", "rccl"]])
+def test_cli_multi_gpu_modes_reproduce_gold_sam(product_build, dy, small_filter, tmp_path, extra):
+    """dream_yara_mapper --gpus / --devices: one context per listed device in one process (the same device may be listed more than once,
+    which is how a one-GPU box rehearses it).  Reads sharded (whole batches round-robin) and bins sharded (FM structures split bin % N,
+    reads -> owners and raw matches -> home through device-to-device copies; with one device and --transport rccl the same sequence runs
+    as self send/receive through RCCL) all give the gold SAM, over 7 batches."""
+    out = str(tmp_path / "out.sam")
+    subprocess.check_call([os.path.join(product_build, "dream_yara_mapper"), "-fi", small_filter, GOLD_INDEX + "/", READS_FA,
+                           "-o", out, "-e", "3", "-rb", "1000", "-t", "3"] + extra)
+    mine = sam_records(out)
+    ref = sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.t1.sam"))
+    assert len(mine) == len(ref)
+    assert [(a, b) for a, b in zip(mine, ref) if a != b] == []
+
+
 def _repeat_genomes(rng, n_bins, length):
     """Random genomes with planted repeat families (to trigger re-seeding of hard reads) and a few Ns."""
     fam = [rng.integers(0, 4, 220, dtype=np.uint8) for _ in range(3)]
@@ -780,7 +795,8 @@ def test_paired_end_on_repeat_families_matches_oracle(dy, ctx, ob, tmp_path):
     assert (o_reads["best_count"] > 100).sum() > 100           # the repeat reads really carry hundreds of co-optimal locations
 
 
-@pytest.mark.parametrize("extra", [[], ["-ll", "320", "-ld", "30", "-s", "2"], ["-ni"]])
+@pytest.mark.parametrize("extra", [[], ["-ll", "320", "-ld", "30", "-s", "2"], ["-ni"], ["--devices", "0,0", "--shard", "bins", "-rb", "1000"],
+                                   ["--devices", "0,0", "-rb", "1000"]])
 def test_cli_paired_end_sam_equals_oracle_cli(product_build, oracle_build, ob, tmp_path, extra):
     """Two reads files -> paired SAM (flags, RNEXT/PNEXT/TLEN, pair MAPQ): the product CLI's text equals the oracle CLI's.
     Parity unpinned by reference fixtures (the reference ships no paired gold output)."""
@@ -799,7 +815,12 @@ def test_cli_paired_end_sam_equals_oracle_cli(product_build, oracle_build, ob, t
     _write_fastq(f1, codes, offs, 0, n_pairs, "/1"); _write_fastq(f2, codes, offs, n_pairs, 2 * n_pairs, "/2")
     mine, ref = str(tmp_path / "mine.sam"), str(tmp_path / "ref.sam")
     subprocess.check_call([os.path.join(product_build, "dream_yara_mapper"), "-fi", fpath, idx_dir + "/", f1, f2, "-o", mine, "-e", "3"] + extra)
-    subprocess.check_call([os.path.join(oracle_build, "oracle_mapper"), "-fi", fpath, idx_dir + "/", f1, f2, "-o", ref, "-e", "3"] + extra)
+    oracle_extra, skip = [], False
+    for tok in extra:                       # the oracle CLI has no devices to choose from
+        if skip: skip = False; continue
+        if tok in ("--devices", "--shard", "--transport", "--gpus"): skip = True; continue
+        oracle_extra.append(tok)
+    subprocess.check_call([os.path.join(oracle_build, "oracle_mapper"), "-fi", fpath, idx_dir + "/", f1, f2, "-o", ref, "-e", "3"] + oracle_extra)
     a, b = sam_records(mine), sam_records(ref)
     assert a[:3 + n_bins - 1] == b[:3 + n_bins - 1]          # header (minus @PG)
     a, b = [r for r in a if r[0] != "@"], [r for r in b if r[0] != "@"]
