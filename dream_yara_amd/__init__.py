@@ -88,6 +88,7 @@ SYMBOLS = [
     ("dy_reads_free", None, [_P]),
     ("dy_ibf_query", C.c_int, [_P, _P, C.c_uint16, _P]),
     ("dy_reads_select_all_bins", C.c_int, [_P, _P, C.c_uint32]),
+    ("dy_suffix_array", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P]),
     ("dy_index_load", C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(_P)]),
     ("dy_index_bins", C.c_uint32, [_P]),
     ("dy_index_contigs", C.c_uint32, [_P]),
@@ -304,6 +305,14 @@ class Index:
         if self.h:
             self.lib.dy_index_free(self.h)
             self.h = None
+
+
+def suffix_array(ctx, text, sigma):
+    """Suffix array of a uint32 text whose sequences end in distinct sentinel symbols (device sort, dy_suffix_array)."""
+    text = np.ascontiguousarray(text, dtype=np.uint32)
+    sa = np.empty(text.size, dtype=np.uint32)
+    _check(ctx.lib.dy_suffix_array(ctx.h, text.ctypes.data, text.size, sigma, sa.ctypes.data))
+    return sa
 
 
 def default_params(**kw):

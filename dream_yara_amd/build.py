@@ -54,7 +54,7 @@ def build(force=False):
         if not os.path.exists(src):
             continue
         if force or not _newer(exe, [src, LIB] + [s for s in srcs if s.endswith((".h", ".hpp"))]):
-            link = [] if tool == "dream_yara_indexer" else ["-L" + CSRC, "-ldyhip", "-Wl,-rpath,$ORIGIN"]
+            link = ["-L" + CSRC, "-ldyhip", "-Wl,-rpath,$ORIGIN"]
             if tool == "dream_yara_mapper":
                 # BAM output, gzip input; the HIP runtime API for the device buffers of the multi-GPU exchange (multi_gpu.hpp; RCCL itself is
                 # loaded on demand).  -D__HIP_PLATFORM_AMD__ only tells the runtime header which of its two API sets to declare.

@@ -1,6 +1,9 @@
 // dream_yara_indexer — builds the per-bin index files (reference src/d_indexer.cpp:127-225,389-473).
 //   dream_yara_indexer [-v] [-t THREADS] -o <OUTPUT PREFIX DIR/> <0.fna> <1.fna> ...
-// File names must be the bin number (reference src/d_indexer.cpp:178-190). Host tool: suffix sorting is not on the mapping path.
+// File names must be the bin number (reference src/d_indexer.cpp:178-190).  The suffix array of every bin is sorted on the GPU
+// (dy_suffix_array) when a device is visible — one context, the bins' host work spread over the -t threads around it — and by the
+// host sorter otherwise (`--sorter host` forces it); the files are byte-identical either way.
+#include "../../include/dyhip.h"
 #include "host_index_build.hpp"
 #include <iostream>
 #include <thread>
@@ -14,7 +17,7 @@ int main(int argc, char ** argv)
 {
     try
     {
-        std::string outPrefix; unsigned threads = 1; bool verbose = false;
+        std::string outPrefix, sorterName = "auto"; unsigned threads = 1; bool verbose = false;
         std::map<unsigned, std::string> files;
         for (int i = 1; i < argc; ++i)
         {
@@ -24,6 +27,7 @@ int main(int argc, char ** argv)
             else if (a == "-t" || a == "--threads") threads = (unsigned)std::stoul(value());
             else if (a == "-td" || a == "--tmp-dir") value();
             else if (a == "-v" || a == "--verbose") verbose = true;
+            else if (a == "--sorter") { sorterName = value(); if (sorterName != "auto" && sorterName != "host" && sorterName != "gpu") throw IoError("--sorter takes auto, host or gpu"); }
             else if (a.size() > 1 && a[0] == '-') throw IoError("unknown option " + a);
             else
             {
@@ -38,6 +42,20 @@ int main(int argc, char ** argv)
         }
         if (outPrefix.empty() || files.empty()) throw IoError("usage: dream_yara_indexer -o <OUTPUT PREFIX> <0.fna> <1.fna> ...");
         std::vector<std::pair<unsigned, std::string> > work(files.begin(), files.end());
+        // the device sorter: one context shared by the worker threads (one sort at a time; the rest of a bin's work overlaps with it)
+        dy_ctx * ctx = nullptr;
+        std::mutex gpuMutex;
+        if (sorterName != "host" && (dy_device_count() > 0 || sorterName == "gpu"))
+            if (dy_ctx_create(0, &ctx) != DY_OK) { if (sorterName == "gpu") throw IoError(dy_last_error()); ctx = nullptr; }
+        SuffixSorter sorter;
+        if (ctx)
+            sorter = [&](const std::vector<u32> & text, u32 sigma) {
+                std::vector<u32> sa(text.size());
+                std::lock_guard<std::mutex> g(gpuMutex);
+                if (dy_suffix_array(ctx, text.data(), text.size(), sigma, sa.data()) != DY_OK) throw IoError(dy_last_error());
+                return sa;
+            };
+        if (verbose) std::cerr << "suffix sorting: " << (ctx ? "device 0" : "host") << "\n";
         std::atomic<size_t> next(0);
         std::string firstError;
         std::mutex errMutex;
@@ -49,7 +67,7 @@ int main(int argc, char ** argv)
                 try
                 {
                     if (verbose) { std::lock_guard<std::mutex> g(errMutex); std::cerr << "[bin " << work[k].first << "] Building reference index ...\n"; }
-                    saveBin(buildBin(readFasta(work[k].second)), outPrefix + std::to_string(work[k].first));
+                    saveBin(buildBin(readFasta(work[k].second), sorter), outPrefix + std::to_string(work[k].first));
                 }
                 catch (std::exception const & e) { std::lock_guard<std::mutex> g(errMutex); if (firstError.empty()) firstError = e.what(); }
             }
@@ -57,6 +75,7 @@ int main(int argc, char ** argv)
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < std::max(1u, threads); ++t) pool.emplace_back(worker);
         for (auto & t : pool) t.join();
+        if (ctx) dy_ctx_free(ctx);
         if (!firstError.empty()) throw IoError(firstError);
     }
     catch (std::exception const & e) { std::cerr << "dream_yara_indexer: " << e.what() << std::endl; return 1; }

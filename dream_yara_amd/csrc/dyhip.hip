@@ -20,6 +20,7 @@
 #include "finalize_kernels.h"
 #include "pe_kernels.h"
 #include "shard_kernels.h"
+#include "sa_kernels.h"
 
 using namespace dy;
 
@@ -1132,6 +1133,51 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
             if (reads->n) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; }
         }
         else if (reads->n) ctx->ibfTimingPending = true;
+    });
+}
+
+int dy_suffix_array(dy_ctx * ctx, const uint32_t * text, uint64_t n, uint32_t sigma, uint32_t * sa_out)
+{
+    return guarded([&] {
+        if (!ctx || (n && (!text || !sa_out))) throw DyError(DY_EINVAL, "dy_suffix_array: NULL argument");
+        if (n >= 0x7FFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "dy_suffix_array: texts of 2^31 symbols or more are not supported");
+        if (sigma == 0 || sigma > 0x40000000u) throw DyError(DY_EINVAL, "dy_suffix_array: alphabet size out of range");
+        if (!n) return;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const u32 N = (u32)n;
+        u32 bits = 1; while ((1ull << bits) <= sigma) ++bits;              // symbols are shifted by +1
+        const u32 q = 63 / bits;
+        DevBuf dText, keysA, keysB, idxA, idxB, rank, flags, tmp, ties;
+        dText.reserve((size_t)N * 4); keysA.reserve((size_t)N * 8); keysB.reserve((size_t)N * 8); idxA.reserve((size_t)N * 4); idxB.reserve((size_t)N * 4);
+        rank.reserve((size_t)N * 4); flags.reserve((size_t)N * 4); ties.reserve(64);
+        HIP_CHECK(hipMemcpyAsync(dText.p, text, (size_t)N * 4, hipMemcpyHostToDevice, st));
+        const dim3 grid((N + 255) / 256), block(256);
+        hipLaunchKernelGGL(k_sa_first_keys, grid, block, 0, st, dText.as<u32>(), N, bits, q, keysA.as<u64>(), idxA.as<u32>());
+        size_t sortBytes = 0, scanBytes = 0;
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, keysA.as<u64>(), keysB.as<u64>(), idxA.as<u32>(), idxB.as<u32>(), (int)N, 0, 64, st));
+        HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, scanBytes, flags.as<u32>(), flags.as<u32>(), MaxU32(), (int)N, st));
+        tmp.reserve(std::max(sortBytes, scanBytes) + 64);
+        int keyBits = (int)std::min<u32>(64, q * bits);
+        for (u32 h = q;; h = h > 0x40000000u ? 0x80000000u : h * 2)
+        {
+            size_t sb = sortBytes;
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, keysA.as<u64>(), keysB.as<u64>(), idxA.as<u32>(), idxB.as<u32>(), (int)N, 0, keyBits, st));
+            HIP_CHECK(hipMemsetAsync(ties.p, 0, 4, st));
+            hipLaunchKernelGGL(k_sa_group_flags, grid, block, 0, st, keysB.as<u64>(), N, flags.as<u32>(), ties.as<u32>());
+            u32 nTies = 0;
+            HIP_CHECK(hipMemcpyAsync(&nTies, ties.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (nTies == 0 || h >= N) break;                                // all ranks unique (h >= n cannot happen with sentinel-terminated texts)
+            size_t cb = scanBytes;
+            HIP_CHECK(hipcub::DeviceScan::InclusiveScan(tmp.p, cb, flags.as<u32>(), flags.as<u32>(), MaxU32(), (int)N, st));
+            hipLaunchKernelGGL(k_sa_scatter_ranks, grid, block, 0, st, idxB.as<u32>(), flags.as<u32>(), N, rank.as<u32>());
+            hipLaunchKernelGGL(k_sa_doubled_keys, grid, block, 0, st, rank.as<u32>(), N, h, keysA.as<u64>(), idxA.as<u32>());
+            keyBits = 64;
+        }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(sa_out, idxB.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
     });
 }
 

@@ -6,6 +6,7 @@
 #include "dy_types.h"
 #include "host_formats.hpp"
 #include <algorithm>
+#include <functional>
 #include <numeric>
 #include <random>
 #include <string>
@@ -105,7 +106,9 @@ struct BuiltBin
     std::vector<u8> drv, ind, val;
 };
 
-inline BuiltBin buildBin(const std::vector<FastaRecord> & recs)
+// `sorter` (optional): suffix array of (text, alphabet size) — the device sort of libdyhip when the indexer runs on a GPU box
+typedef std::function<std::vector<u32>(const std::vector<u32> &, u32)> SuffixSorter;
+inline BuiltBin buildBin(const std::vector<FastaRecord> & recs, const SuffixSorter & sorter = SuffixSorter())
 {
     BuiltBin B;
     B.count = recs.size();
@@ -143,7 +146,7 @@ inline BuiltBin buildBin(const std::vector<FastaRecord> & recs)
         }
         start[cnt] = p;
     }
-    std::vector<u32> sa = suffixArrayDoubling(T, cnt + 4);
+    std::vector<u32> sa = sorter ? sorter(T, cnt + 4) : suffixArrayDoubling(T, cnt + 4);
 
     // row -> (contig, offset); BWT with the sentinel substitute; sentinel rows
     std::vector<u32> contigOf(n);

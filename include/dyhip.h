@@ -135,6 +135,12 @@ typedef struct {
 int  dy_index_get_info(const dy_index *idx, dy_index_info *info);
 void dy_index_free(dy_index *idx);
 
+/* ---- index construction (dream_yara_indexer) ----------------------------------------------------------- */
+/* Suffix array of text[0, n) over symbols [0, sigma), every sequence terminated by its own sentinel symbol (so no two suffixes
+ * compare equal), built on the device.  Stands where the reference lets SeqAn construct the FM index of a bin's reversed contigs
+ * (reference src/d_indexer.cpp:278-333); BWT, rank dictionary and the sampled suffix array follow from it on the host. */
+int  dy_suffix_array(dy_ctx *ctx, const uint32_t *text, uint64_t n, uint32_t sigma, uint32_t *sa_out);
+
 /* ---- mapping ----------------------------------------------------------------------------------------- */
 typedef struct {
     float    error_rate;      /* Options::errorRate  (reference src/mapper.h:68,99)  */

@@ -1057,6 +1057,46 @@ def test_bins_with_more_than_255_contigs_match_oracle(dy, ctx, ob, tmp_path, n_c
     assert dev[0]["primary"]["contig"][mapped].max() > (65535 if n_contigs > 30000 else 255)        # ids beyond the narrower type are reported
 
 
+def test_gpu_indexer_reproduces_gold_bytes_and_the_host_sorter(product_build, dy, ctx, tmp_path):
+    """dream_yara_indexer sorts the suffixes of every bin on the device (dy_suffix_array: prefix doubling over hipcub radix
+    sorts).  The 768 files it writes for the 64 gold genomes are the gold files byte for byte; on texts that need many doubling rounds
+    (a 30 kbp homopolymer run, planted repeats, 300 short contigs with their sentinels) the device's suffix array equals the host sorter's."""
+    import filecmp
+    names, codes, offs = read_fasta_codes(GENOMES_FA)
+    fa_dir = tmp_path / "fa"; fa_dir.mkdir()
+    for b in range(64):
+        with open(fa_dir / ("%d.fna" % b), "wb") as f:
+            f.write(b">" + names[b].encode() + b"\n" + np.frombuffer(b"ACGTN", np.uint8)[codes[int(offs[b]):int(offs[b + 1])]].tobytes() + b"\n")
+    out = tmp_path / "idx"; out.mkdir()
+    log = subprocess.run([os.path.join(product_build, "dream_yara_indexer"), "-v", "--sorter", "gpu", "-t", "8", "-o", str(out) + "/"] +
+                         [str(fa_dir / ("%d.fna" % b)) for b in range(64)], check=True, capture_output=True, text=True).stderr
+    assert "suffix sorting: device 0" in log
+    files = sorted(os.listdir(GOLD_INDEX))
+    assert len(files) == 768
+    for n in files:
+        assert filecmp.cmp(os.path.join(GOLD_INDEX, n), str(out / n), shallow=False), n
+    # many doubling rounds: homopolymer run + repeats; many sentinels
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 4, 200000, dtype=np.uint8)
+    g[1000:31000] = 0
+    g[60000:61000] = g[90000:91000]
+    a = tmp_path / "a"; a.mkdir(); b = tmp_path / "b"; b.mkdir()
+    with open(tmp_path / "0.fna", "wb") as f:
+        f.write(b">hard\n" + np.frombuffer(b"ACGTN", np.uint8)[g].tobytes() + b"\n")
+        for i in range(300):
+            c = rng.integers(0, 4, int(rng.integers(30, 120)), dtype=np.uint8)
+            f.write(b">c%d\n" % i + np.frombuffer(b"ACGTN", np.uint8)[c].tobytes() + b"\n")
+    subprocess.check_call([os.path.join(product_build, "dream_yara_indexer"), "--sorter", "gpu", "-o", str(a) + "/", str(tmp_path / "0.fna")])
+    subprocess.check_call([os.path.join(product_build, "dream_yara_indexer"), "--sorter", "host", "-o", str(b) + "/", str(tmp_path / "0.fna")])
+    for n in sorted(os.listdir(a)):
+        assert filecmp.cmp(str(a / n), str(b / n), shallow=False), n
+    # the ABI entry on its own: two sequences with their sentinels
+    text = np.array([2 + 1, 2 + 0, 2 + 1, 2 + 0, 0, 2 + 0, 2 + 1, 1], dtype=np.uint32)       # "CACA$0 AC$1" over {$0,$1,A,C,G,T}
+    sa = dy.suffix_array(ctx, text, 6)
+    want = sorted(range(text.size), key=lambda i: text[i:].tolist())
+    assert sa.tolist() == want
+
+
 # ---------------------------------------------------------------------------------------------- error behaviour of the boundary
 def test_abi_error_codes_and_messages(dy, ctx, small_filter, tmp_path):
     """Errors come back as DY_E* codes with the reference's wording where it has one (reference src/mapper.h:453-454,
