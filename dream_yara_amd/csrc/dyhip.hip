@@ -143,7 +143,7 @@ struct dy_ctx
     DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor;
+           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
     size_t poolCap = 0;
     PinnedBuf hostUp;                   // staging of dy_reads_upload
     PinnedBuf sparePinned[9];           // host arrays of fetched results, handed back by dy_result_free (hipHostMalloc costs milliseconds)
@@ -341,13 +341,22 @@ __global__ void k_fill_masks(u64 * masks, u32 nReads, u32 W, u32 nBins)
 }
 
 template <int NW>
-static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink)
+static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink, u32 maxSeedLen)
 {
     hipLaunchKernelGGL(k_extend<NW>, dim3(((nItems + 255) / 256 + 7) / 8 * 8), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
                        nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>());
     // re-seeded items: list-driven, spread thinly over a full grid (normally a tiny fraction of the items)
-    hipLaunchKernelGGL(k_extend_hard<NW>, dim3(2048), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(),
-                       ctx->itemBin.as<u16>(), S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>());
+    // -y full: the edit-distance trie walk keeps one frame per level in a slab, one slice per wavefront of this grid
+    const u32 hardBlocks = 2048;
+    EditFrame * slab = nullptr; u32 stride = 0;
+    if (mp.sensitivity == 2)
+    {
+        stride = maxSeedLen + 8;
+        ctx->editSlab.reserve((size_t)hardBlocks * 4 * stride * sizeof(EditFrame) + 64);
+        slab = ctx->editSlab.as<EditFrame>();
+    }
+    hipLaunchKernelGGL(k_extend_hard<NW>, dim3(hardBlocks), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(),
+                       ctx->itemBin.as<u16>(), S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), slab, stride);
 }
 
 // Work list (bin-major): (read,bin) items of the masks on `reads` -> ctx->itemRead / itemBin / binStart (+ the local sortedBins() rank).
@@ -439,10 +448,12 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             sink.overflow = ctx->counters.as<u32>() + 1; sink.readMatchCount = ctx->readMatchCount.as<u32>();
             if (nItems)
             {
-                if (nw <= 2) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink);
-                else if (nw <= 4) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink);
-                else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink);
-                else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink);
+                // the longest seed a read of the batch can be cut into: a short read with few errors may be ONE seed (ceil((e + 1) / 3) = 1)
+                const u32 maxSeedLen = reads->maxLen;
+                if (nw <= 2) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
+                else if (nw <= 4) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
+                else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
+                else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 HIP_CHECK(hipGetLastError());
             }
             HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
@@ -1342,7 +1353,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
     return guarded([&] {
         if (!ctx || !idx || !reads || !p || !out) throw DyError(DY_EINVAL, "dy_map_reads: NULL argument");
         if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
-        if (p->sensitivity > 1) throw DyError(DY_EUNSUPPORTED, "sensitivity 'full' (edit-distance seeds) is not implemented");
+        if (p->sensitivity > 2) throw DyError(DY_EINVAL, "sensitivity must be 0 (low), 1 (high) or 2 (full)");
         if (idx->sharded) throw DyError(DY_EINVAL, "this index holds a shard of the bins: use dy_map_bins / dy_finalize_raw");
         if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
         HIP_CHECK(hipSetDevice(ctx->device));
@@ -1640,7 +1651,7 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
     return guarded([&] {
         if (!ctx || !idx || !reads || !p || !bin_loads || !n_raw) throw DyError(DY_EINVAL, "dy_map_bins: NULL argument");
         if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
-        if (p->sensitivity > 1) throw DyError(DY_EUNSUPPORTED, "sensitivity 'full' (edit-distance seeds) is not implemented");
+        if (p->sensitivity > 2) throw DyError(DY_EINVAL, "sensitivity must be 0 (low), 1 (high) or 2 (full)");
         if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
         const bool paired = p->paired != 0;
         if (paired && !reads->pairLayout) throw DyError(DY_EINVAL, "a paired dy_map_bins needs a batch built by dy_reads_from_device_paired");

@@ -392,22 +392,26 @@ struct MatchSink
 // extend() + _addMatchImpl() for one located seed occurrence (reference src/find_extender.h:262-403, src/mapper_extender.h:293-308).
 // `seq` is the read sequence of the seed's strand (forward or reverse complement), readable front to back.
 // `emit(matchBegin, matchLength, errors)` is called once if the occurrence extends to a match.
+// `edit` (-y full, TSeedsDistance = EditDistance, reference src/find_extender.h:314-322): no _checkSeed, and the left extension starts at
+// the seed's END, re-aligning the seed region as well.
 template <int NW, typename TEmit>
-__device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
-                                                  const u8 * __restrict__ seq, u32 len, u32 needleBegin, u32 maxErrors, TEmit emit)
+__device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBeginSeed, u32 seedLen,
+                                                  const u8 * __restrict__ seq, u32 len, u32 needleBeginSeed, u32 maxErrors, bool edit, TEmit emit)
 {
     const u8 * __restrict__ ctg = binContigs + binLimits[contig];
     const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
-    const u32 hayEnd = hayBegin + seedLen, needleEnd = needleBegin + seedLen;
+    const u32 hayEnd = hayBeginSeed + seedLen, needleEnd = needleBeginSeed + seedLen;
     // _checkSeed: recount against the real contig (Ns were randomised in the index); the early-out of the reference's
     // loop only matters when the total exceeds maxErrors, which fails either way
-    u32 errors = countMismatches(ctg + hayBegin, seq + needleBegin, (int)seedLen);
+    u32 errors = edit ? 0u : countMismatches(ctg + hayBeginSeed, seq + needleBeginSeed, (int)seedLen);
     if (errors > maxErrors) return;
+    // anchor of the left extension
+    const u32 hayBegin = edit ? hayEnd : hayBeginSeed, needleBegin = edit ? needleEnd : needleBeginSeed;
     u32 matchBegin = hayBegin;
     if (needleBegin > 0)
     {   // _extendLeft on the reversed infixes
-        const u32 leftOffset = needleBegin + (maxErrors - errors);
-        const u32 leftBegin = hayBegin > leftOffset ? hayBegin - leftOffset : 0;
+        const u32 leftOffset = needleBeginSeed + (maxErrors - errors);
+        const u32 leftBegin = hayBeginSeed > leftOffset ? hayBeginSeed - leftOffset : 0;
         const int hayLen = (int)(hayBegin - leftBegin), ndlLen = (int)needleBegin;
         const int lcp = lcpBackward(ctg + hayBegin, seq + needleBegin, hayLen < ndlLen ? hayLen : ndlLen);
         if (lcp == ndlLen)
@@ -439,9 +443,9 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
     u32 matchEnd = hayEnd;
     if (needleEnd < len)
     {   // _extendRight, last base held out
-        const u32 rightOffset = len - needleBegin + (maxErrors - errors);
+        const u32 rightOffset = len - needleBeginSeed + (maxErrors - errors);
         u32 rightEnd = clen;
-        if (rightEnd > hayBegin + rightOffset) rightEnd = hayBegin + rightOffset;
+        if (rightEnd > hayBeginSeed + rightOffset) rightEnd = hayBeginSeed + rightOffset;
         const int hayLen = (int)(rightEnd - hayEnd), ndlLen = (int)(len - needleEnd);
         const int lcp = lcpForward(ctg + hayEnd, seq + needleEnd, hayLen < ndlLen ? hayLen : ndlLen);
         if (lcp == ndlLen)
@@ -485,9 +489,9 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
 template <int NW>
 __device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
                                  const u8 * __restrict__ seq, u32 len, u32 strand,
-                                 u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink)
+                                 u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink, bool edit)
 {
-    extendOccurrenceT<NW>(binContigs, binLimits, contig, hayBegin, seedLen, seq, len, needleBegin, maxErrors, [&](u32 matchBegin, u32 matchLen, u32 errors) {
+    extendOccurrenceT<NW>(binContigs, binLimits, contig, hayBegin, seedLen, seq, len, needleBegin, maxErrors, edit, [&](u32 matchBegin, u32 matchLen, u32 errors) {
         RawMatch m;
         m.read = read; m.begin = matchBegin; m.len = (u16)matchLen; m.errors = (u8)errors; m.strand = (u8)strand;
         m.bin = (u16)bin; m.contig = (u16)contig;
@@ -534,6 +538,61 @@ __device__ void fmBacktrack(const BinView & b, const u8 * __restrict__ seq, u32 
         u32 lo = f.lo, hi = f.hi;
         if (!fmStep(b, lo, hi, sc)) { --level; continue; }
         f.lo = lo; f.hi = hi; f.d += 1; f.alt = 0;
+    }
+}
+
+// Edit-distance backtracking over the FM trie (-y full: SeqAn find(..., Backtracking<EditDistance>), reference src/mapper.h:607-649) — the
+// enumeration defined in oracle/dyo_mapper.hpp fmSearchEdit (PARITY UNPINNED, see there): depth-first, children A, C, G, T, every node
+// carries the band |i - depth| <= maxErr of the DP column D[i] = ed(seed[0..i), path); leaf(lo, hi) for every node with D[seedLen] <= maxErr.
+// One frame per trie level: the stack (seedLen + maxErr + 2 frames) lives in a global slab owned by the wavefront, which walks in step.
+struct EditFrame { u32 lo, hi; u8 alt; u8 band[5]; u16 pad; };
+static_assert(sizeof(EditFrame) == 16, "frame slab stride");
+template <typename TLeaf>
+__device__ void fmBacktrackEdit(const BinView & b, const u8 * __restrict__ seq, u32 len, u32 strand, u32 off, u32 seedLen, u32 maxErr, EditFrame * __restrict__ st, TLeaf leaf)
+{
+    const u32 E = maxErr, BW = 2 * E + 1, INF = E + 1;
+    int level = 0;
+    st[0].lo = 0; st[0].hi = b.n; st[0].alt = 0;
+    for (u32 t = 0; t < 5; ++t) st[0].band[t] = (t < BW && t >= E) ? (u8)(t - E) : (u8)INF;
+    while (level >= 0)
+    {
+        EditFrame f = st[level];
+        if (f.alt == 0 && level > 0)
+        {
+            const int t = (int)seedLen - level + (int)E;
+            if (t >= 0 && t < (int)BW && f.band[t] <= E) leaf(f.lo, f.hi);
+        }
+        if (f.alt == 4 || (u32)level == seedLen + E) { --level; continue; }
+        const u32 c = f.alt;
+        st[level].alt = (u8)(c + 1);
+        u8 nb[5]; u32 best = INF;
+        for (u32 t = 0; t < 5; ++t)
+        {
+            u32 v = INF;
+            const int i = level + 1 - (int)E + (int)t;
+            if (t < BW && i >= 0 && i <= (int)seedLen)
+            {
+                if (i == 0) v = (u32)level + 1;
+                else
+                {
+                    const u32 sc = readBase(seq, len, strand, off + (u32)i - 1);
+                    const u32 diag = (u32)f.band[t] + ((sc == c && sc < 4) ? 0u : 1u);
+                    const u32 up = t + 1 < BW ? (u32)f.band[t + 1] + 1 : INF;
+                    const u32 left = t > 0 ? (u32)nb[t - 1] + 1 : INF;
+                    v = min(diag, min(up, left));
+                }
+                if (v > INF) v = INF;
+            }
+            nb[t] = (u8)v;
+            best = min(best, v);
+        }
+        if (best > E) continue;
+        u32 lo = f.lo, hi = f.hi;
+        if (!fmStep(b, lo, hi, c)) continue;
+        ++level;
+        EditFrame g; g.lo = lo; g.hi = hi; g.alt = 0; g.pad = 0;
+        for (u32 t = 0; t < 5; ++t) g.band[t] = nb[t];
+        st[level] = g;
     }
 }
 
@@ -684,7 +743,8 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
             ++row;
             const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
             if (clen - x >= seedLen)
-                extendOccurrence<NW>(binContigs, binLimits, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink);
+                extendOccurrence<NW>(binContigs, binLimits, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink,
+                                     prm.sensitivity == 2);
         }
     }
 }
@@ -700,8 +760,9 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
 // minimum over the lanes is taken after each rank.  Matches go to the pool step by step (st's buffers stay unused).
 template <int NW>
 __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
-                                   const uint2 * __restrict__ hits0, const MatchSink & sink, ItemState & st, u32 lane)
+                                   const uint2 * __restrict__ hits0, const MatchSink & sink, ItemState & st, u32 lane, EditFrame * __restrict__ editStack)
 {
+    const bool edit = prm.sensitivity == 2;
     const u8 * seq = rd.seqs + rd.offs[read];
     const u8 * seqRc = rd.seqsRc + rd.offs[read];
     const u32 len = (u32)(rd.offs[read + 1] - rd.offs[read]);
@@ -722,7 +783,8 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
             for (u32 k = 0; k < cntB; ++k)
             {
                 u32 c = 0;
-                fmBacktrack(b, seq, len, strand, (cntB - 1 - k) * seedLen, seedLen, E, [&](u32 lo, u32 hi) { c += hi - lo; });
+                if (edit && E > 0) fmBacktrackEdit(b, seq, len, strand, (cntB - 1 - k) * seedLen, seedLen, E, editStack, [&](u32 lo, u32 hi) { c += hi - lo; });
+                else fmBacktrack(b, seq, len, strand, (cntB - 1 - k) * seedLen, seedLen, E, [&](u32 lo, u32 hi) { c += hi - lo; });
                 counts[strand][k] = c;
             }
         u32 done[2] = {0, 0};
@@ -739,7 +801,7 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                 done[strand] |= 1u << bestId;
                 const u32 off = (cntB - 1 - bestId) * seedLen;
                 const u8 * sq = strand ? seqRc : seq;
-                fmBacktrack(b, seq, len, strand, off, seedLen, E, [&](u32 lo, u32 hi) {
+                auto onLeaf = [&](u32 lo, u32 hi) {
                     for (u32 base = lo; base < hi; base += 64)
                     {   // lanes beyond the leaf idle for this step; the loop bound is the same in every lane
                         const u32 row = base + lane;
@@ -750,7 +812,7 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                             fmLocate(b, row, contig, x);
                             const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
                             if (clen - x >= seedLen)      // suffixLength >= seedLength
-                                extendOccurrenceT<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, sq, len, off, readErrors,
+                                extendOccurrenceT<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, sq, len, off, readErrors, edit,
                                                       [&](u32 matchBegin, u32 matchLen, u32 errors) { got = 1; mBegin = matchBegin; mLen = matchLen; mErrors = errors; mContig = contig; });
                         }
                         // every lane holds at most one new match of the SAME read: one pool reservation and one per-read count update per
@@ -776,7 +838,9 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                             if (got && mErrors < st.minErrors) st.minErrors = mErrors;
                         }
                     }
-                });
+                };
+                if (edit && E > 0) fmBacktrackEdit(b, seq, len, strand, off, seedLen, E, editStack, onLeaf);
+                else fmBacktrack(b, seq, len, strand, off, seedLen, E, onLeaf);
             }
             // ReadsContext::minErrors is one value per read
             u32 mn = st.minErrors;
@@ -839,17 +903,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? D
 template <int NW>
 __global__ __launch_bounds__(256) void k_extend_hard(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
                                                      u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
-                                                     const u32 * __restrict__ hardCount, const u32 * __restrict__ hardList)
+                                                     const u32 * __restrict__ hardCount, const u32 * __restrict__ hardList,
+                                                     EditFrame * __restrict__ editSlab, u32 editStride)
 {
     const u32 lane = threadIdx.x & 63;
     const u32 n = *hardCount;
     const u32 totalWaves = gridDim.x * (blockDim.x >> 6), waveId = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    EditFrame * editStack = editSlab ? editSlab + (size_t)waveId * editStride : nullptr;
     for (u32 i = waveId; i < n; i += totalWaves)
     {   // one wavefront per re-seeded item (see extendHardItemWave)
         ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
         const u32 item = hardList[i];
         const u32 read = itemRead[item];
-        extendHardItemWave<NW>(ix, rd, item, read, itemBin[item], S0, prm, hits0, sink, st, lane);
+        extendHardItemWave<NW>(ix, rd, item, read, itemBin[item], S0, prm, hits0, sink, st, lane, editStack);
     }
 }
 

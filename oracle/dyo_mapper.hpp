@@ -203,6 +203,65 @@ inline void fmSearch(const FMIndex & fm, const u8 * seed, unsigned len, unsigned
     }
 }
 
+// Edit-distance backtracking of one seed — `-y full`, reference src/mapper.h:607-649 with TSeedsDistance = EditDistance
+// (src/d_mapper.cpp:417-436): find(index, seeds, errors, delegate, Backtracking<EditDistance>).  PARITY UNPINNED: SeqAn's enumeration
+// lives in the absent submodule and no fixture uses -y full.  Defined here as: depth-first over the FM trie (children A, C, G, T), every
+// node carrying the band |i - depth| <= maxErr of the DP column D[i] = ed(seed[0..i), path); a node is reported, with errors = D[len],
+// when D[len] <= maxErr, and expanded while some band cell is <= maxErr.  Nested nodes are separate hits (their occurrences end at
+// different text positions, and the END of an occurrence is what the extension anchors on, src/mapper_extender.h:263-285).
+// What the reads' final records depend on is the set of anchors — every text position where an occurrence within maxErr edits of the
+// seed ends — which any complete enumeration yields; multiplicities only enter the seed ranking, whose order cannot change the matches
+// within the reported strata (the early exit waits for rank * (E + 1) >= minErrors + strata, by which every such match has been
+// reached through some seed whatever the order) but can change which representative of a duplicated location survives.
+inline void fmSearchEdit(const FMIndex & fm, const u8 * seed, unsigned len, unsigned maxErr, u32 seedId, std::vector<Hit> & hits)
+{
+    const unsigned E = maxErr, BW = 2 * E + 1, INF = E + 1;
+    struct Frame { u32 lo, hi; u8 alt; u8 band[5]; };
+    std::vector<Frame> st(len + E + 2);
+    int level = 0;
+    st[0].lo = 0; st[0].hi = fm.n; st[0].alt = 0;
+    for (unsigned t = 0; t < BW; ++t) st[0].band[t] = t >= E ? (u8)(t - E) : (u8)INF;     // D[i] = i at depth 0, i = t - E
+    while (level >= 0)
+    {
+        Frame & f = st[level];
+        if (f.alt == 0 && level > 0)
+        {   // first visit: report when the whole seed is consumed within the budget
+            const int t = (int)len - level + (int)E;
+            if (t >= 0 && t < (int)BW && f.band[t] <= E) hits.push_back(Hit{f.lo, f.hi, seedId, f.band[t]});
+        }
+        if (f.alt == 4 || (unsigned)level == len + E) { --level; continue; }
+        const u8 c = f.alt++;
+        // child band: cell t' stands for i' = level + 1 - E + t'
+        u8 nb[5]; unsigned best = INF;
+        for (unsigned t = 0; t < BW; ++t)
+        {
+            const int i = level + 1 - (int)E + (int)t;
+            unsigned v = INF;
+            if (i >= 0 && i <= (int)len)
+            {
+                if (i == 0) v = (unsigned)level + 1;                                        // nothing of the seed against level + 1 text characters
+                else
+                {
+                    const unsigned diag = f.band[t] + ((seed[i - 1] == c && c < 4) ? 0u : 1u);           // parent cell i - 1 sits at the same t
+                    const unsigned up = t + 1 < BW ? (unsigned)f.band[t + 1] + 1 : INF;                 // parent cell i: the text character stays unmatched
+                    const unsigned left = t > 0 ? (unsigned)nb[t - 1] + 1 : INF;                          // child cell i - 1: the seed character stays unmatched
+                    v = std::min(diag, std::min(up, left));
+                }
+                if (v > INF) v = INF;
+            }
+            nb[t] = (u8)v;
+            best = std::min(best, v);
+        }
+        if (best > E) continue;
+        const u32 lo = fm.lf(f.lo, c), hi = fm.lf(f.hi, c);
+        if (lo >= hi) continue;
+        Frame & g = st[level + 1];
+        g.lo = lo; g.hi = hi; g.alt = 0;
+        for (unsigned t = 0; t < BW; ++t) g.band[t] = nb[t];
+        ++level;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // Banded prefix edit distance (stands in for SeqAn Myers<AlignTextBanded<FindPrefix,NMatchesNone_,NMatchesNone_>>,
 // SURVEY.md C.2): for every text prefix length j>=0 with ed(needle, text[0..j)) <= k call f(j-1, dist) in
@@ -244,23 +303,29 @@ inline void prefixEditSearch(TGetN needle, int m, TGetT text, int t, int k, F &&
 // ----------------------------------------------------------------------------
 inline bool extendSeed(const u8 * contig, u64 contigLen, const u8 * read, unsigned readLen,
                        u64 hayBegin, u64 hayEnd, unsigned needleBegin, unsigned needleEnd, unsigned maxErrors,
-                       u64 & matchBegin, u64 & matchEnd, unsigned & matchErrors)
+                       u64 & matchBegin, u64 & matchEnd, unsigned & matchErrors, bool editSeeds = false)
 {
     matchErrors = 0;
-    // _checkSeed :87-106
     if (hayEnd - hayBegin != needleEnd - needleBegin) return false;
+    // Hamming seeds: _checkSeed :87-106, then the left extension starts at the seed's begin.  Edit-distance seeds (-y full): no check,
+    // the left extension starts at the seed's END and re-aligns the seed region too (:314-322: haystackLeftEnd / needleLeftEnd).
+    u64 leftAnchorHay = hayEnd; unsigned leftAnchorNeedle = needleEnd;
+    if (!editSeeds)
     {
         u64 h = hayBegin; unsigned q = needleBegin;
         for (; h != hayEnd && matchErrors <= maxErrors; ++h, ++q)
             matchErrors += !dnaEq(contig[h], read[q]);
         if (!(h == hayEnd && matchErrors <= maxErrors)) return false;
+        leftAnchorHay = hayBegin; leftAnchorNeedle = needleBegin;
     }
-    matchBegin = hayBegin;
+    matchBegin = leftAnchorHay;
     // ---- extend left :334-366, _extendLeft :112-174
-    if (needleBegin > 0)
+    if (leftAnchorNeedle > 0)
     {
         u64 leftOffset = needleBegin + (maxErrors - matchErrors);
         u64 leftBegin = hayBegin > leftOffset ? hayBegin - leftOffset : 0;
+        const u64 hayBeginSeed = hayBegin; const unsigned needleBeginSeed = needleBegin;
+        hayBegin = leftAnchorHay; needleBegin = leftAnchorNeedle;          // the anchor of the reversed views below
         // reversed views: hay[i] = contig[hayBegin-1-i], i < hayLen; needle[i] = read[needleBegin-1-i]
         int hayLen = (int)(hayBegin - leftBegin), ndlLen = (int)needleBegin;
         int lcp = 0;
@@ -283,6 +348,7 @@ inline bool extendSeed(const u8 * contig, u64 contigLen, const u8 * read, unsign
             matchBegin -= (u64)(endPos + lcp);
             if (matchErrors > maxErrors) return false;
         }
+        hayBegin = hayBeginSeed; needleBegin = needleBeginSeed;
     }
     // ---- extend right :369-396, _extendRight :180-254
     matchEnd = hayEnd;
@@ -426,7 +492,8 @@ private:
         for (int s = 0; s < 2; ++s)
             for (unsigned id = 0; id < ss.count; ++id)
             {
-                fmSearch(bin.fm, seqs[s] + ss.offset(id), ss.length, errors, id, hits[s]);
+                if (errors > 0 && opt.sensitivity == FULL) fmSearchEdit(bin.fm, seqs[s] + ss.offset(id), ss.length, errors, id, hits[s]);
+                else fmSearch(bin.fm, seqs[s] + ss.offset(id), ss.length, errors, id, hits[s]);
                 if (stats) stats->seeds++;
             }
         if (stats) stats->hits += hits[0].size() + hits[1].size();
@@ -474,7 +541,7 @@ private:
             u64 mb, me; unsigned errs;
             if (stats) stats->extended++;
             if (!extendSeed(bin.contigs.seq(contig), clen, read, readLen, hayBegin, hayBegin + ss.length,
-                            needleBegin, needleEnd, maxErrors, mb, me, errs))
+                            needleBegin, needleEnd, maxErrors, mb, me, errs, opt.sensitivity == FULL))
                 continue;
             Match m;
             m.readId = readId; m.contigId = contig; m.isRev = isRev;

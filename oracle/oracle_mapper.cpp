@@ -40,7 +40,6 @@ int main(int argc, char ** argv)
         }
         if (pos.size() != 2 && pos.size() != 3) throw std::runtime_error("usage: oracle_mapper [OPTIONS] <INDEX DIR> <READS> [<READS2>]");
         const bool paired = pos.size() == 3;
-        if (opt.sensitivity == FULL) throw std::runtime_error("-y full (edit-distance seeds) is not restated");
         for (int i = 0; i < argc; ++i) { if (i) opt.commandLine += ' '; opt.commandLine += argv[i]; }
         std::string dir = pos[0];
         while (dir.size() > 1 && dir.back() == '/') dir.pop_back();

@@ -440,7 +440,11 @@ def _sample_reads(rng, genomes, fam, n, L, err):
 
 
 @pytest.mark.parametrize("L,e,strata,sens,use_filter", [(100, 3, 0, 1, True), (100, 3, 3, 1, True), (100, 5, 0, 0, True), (150, 5, 0, 1, True),
-                                                        (60, 4, 2, 1, False), (36, 0, 0, 1, True)])
+                                                        (60, 4, 2, 1, False), (36, 0, 0, 1, True),
+                                                        # -y full (sens 2): edit-distance seeds for the re-seeded reads and the edit-mode extension anchor for
+                                                        # every read.  PARITY UNPINNED: SeqAn's Backtracking<EditDistance> enumeration is not in the reference
+                                                        # tree and no fixture uses -y full; device == oracle (oracle/dyo_mapper.hpp fmSearchEdit defines it)
+                                                        (100, 3, 0, 2, True), (100, 5, 2, 2, True), (150, 5, 0, 2, False), (60, 4, 0, 2, True)])
 def test_map_matches_oracle_on_repeats_and_indels(dy, ctx, ob, tmp_path, L, e, strata, sens, use_filter):
     rng = np.random.default_rng(L * 1000 + e * 10 + strata)
     n_bins = 6
@@ -505,26 +509,39 @@ def test_pool_overflow_retry_with_reseeded_reads(dy, ob, tmp_path):
     assert_results_equal(dev, (o_reads, o_matches, o_cigars))
 
 
-def test_variable_length_batch_matches_oracle(dy, ctx, ob, tmp_path):
+@pytest.mark.parametrize("sens", [1, 2])
+def test_variable_length_batch_matches_oracle(dy, ctx, ob, tmp_path, sens):
+    """Reads of 30..260 bases in one batch, a quarter of them from a planted repeat family (re-seeded: > 300 seed hits), so that seeds of
+    every length the batch allows go through the backtracking — with -y full (sens 2) through the edit-distance trie walk, whose frame
+    stack is sized by the longest read of the batch (a short read with few errors is cut into a single seed)."""
     rng = np.random.default_rng(99)
-    genomes = [rng.integers(0, 4, 30000, dtype=np.uint8) for _ in range(4)]
+    genomes = [rng.integers(0, 4, 30000 if b else 150000, dtype=np.uint8) for b in range(4)]
+    fam = rng.integers(0, 4, 270, dtype=np.uint8)
+    for c in range(420):
+        f = fam.copy(); m = rng.random(f.size) < 0.01; f[m] = (f[m] + 1) & 3
+        genomes[0][c * 300:c * 300 + f.size] = f
     idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
     for b, g in enumerate(genomes):
         ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
     reads = []
     for i in range(800):
         L = int(rng.integers(30, 260))
-        b = int(rng.integers(0, 4)); s = int(rng.integers(0, 30000 - L))
-        r = genomes[b][s:s + L].copy()
+        if i % 4 == 0:
+            s = int(rng.integers(0, fam.size - L)) if L < fam.size else 0
+            r = fam[s:s + L].copy()
+        else:
+            b = int(rng.integers(0, 4)); s = int(rng.integers(0, genomes[b].size - L))
+            r = genomes[b][s:s + L].copy()
         for _ in range(int(rng.integers(0, 3))):
             p = int(rng.integers(0, L)); r[p] = (r[p] + 1) & 3
         if i % 2: r = r[::-1].copy(); r = 3 - r
         reads.append(r)
     codes = np.concatenate(reads); offs = np.zeros(801, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
     er = np.float32(0.04)
-    dev, _ = device_map(dy, ctx, idx_dir, 4, None, codes, offs, er)
+    dev, stats = device_map(dy, ctx, idx_dir, 4, None, codes, offs, er, sensitivity=sens)
     oidx = ob.OracleIndex(idx_dir, 4)
-    o = ob.map_batch(oidx, None, codes, offs, er)
+    o = ob.map_batch(oidx, None, codes, offs, er, sensitivity=sens, threads=8)
+    assert stats["hard_items"] > 100 and stats["raw_matches"] == o[3]["raw_matches"]
     assert_results_equal(dev, o[:3])
     oidx.close()
 
@@ -1113,9 +1130,9 @@ def test_abi_error_codes_and_messages(dy, ctx, small_filter, tmp_path):
     with pytest.raises(dy.DyError) as e:                      # odd number of reads in a paired batch
         dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03), paired=1))
     assert e.value.code == EINVAL
-    with pytest.raises(dy.DyError) as e:                      # -y full
-        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03), sensitivity=2))
-    assert e.value.code == EUNSUPPORTED and "full" in str(e.value)
+    with pytest.raises(dy.DyError) as e:                      # there is no sensitivity beyond full
+        dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.03), sensitivity=3))
+    assert e.value.code == EINVAL and "sensitivity" in str(e.value)
     with pytest.raises(dy.DyError) as e:
         dy.map_reads(ctx, idx, reads, dy.default_params(error_rate=np.float32(0.5)))
     assert e.value.code == EINVAL
@@ -1141,6 +1158,18 @@ def test_abi_error_codes_and_messages(dy, ctx, small_filter, tmp_path):
     res.close(); f2.close(); ibf.close(); reads.close(); idx.close()
 
 
+def test_cli_sensitivity_full_equals_oracle_cli(product_build, oracle_build, small_filter, tmp_path):
+    """-y full through the command line on the gold data: the product's SAM equals the oracle CLI's (PARITY UNPINNED: the reference's tests
+    never run -y full).  Every extension uses the edit-distance anchor in this mode, so a few records differ from the -y high gold file."""
+    mine, ref = str(tmp_path / "mine.sam"), str(tmp_path / "ref.sam")
+    subprocess.check_call([os.path.join(product_build, "dream_yara_mapper"), "-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-o", mine, "-e", "3", "-y", "full"])
+    subprocess.check_call([os.path.join(oracle_build, "oracle_mapper"), "-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-o", ref, "-e", "3", "-y", "full"])
+    a, b = sam_records(mine), sam_records(ref)
+    assert len(a) == len(b) and [(x, y) for x, y in zip(a, b) if x != y] == []
+    gold = sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.t1.sam"))
+    assert sum(1 for x, y in zip(a, gold) if x != y) < len(gold) // 20          # the same reads map, a handful of alignments differ
+
+
 def test_cli_errors_exit_1_with_the_tool_name(product_build, small_filter, tmp_path):
     exe = os.path.join(product_build, "dream_yara_mapper")
     def run(args):
@@ -1152,8 +1181,8 @@ def test_cli_errors_exit_1_with_the_tool_name(product_build, small_filter, tmp_p
     assert rc == 1 and "unknown option" in err
     rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-e", "11"])
     assert rc == 1 and "out of range" in err
-    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-y", "full"])
-    assert rc == 1 and "not implemented" in err
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-y", "fullest"])
+    assert rc == 1 and "sensitivity" in err
     rc, err = run(["-fi", str(tmp_path / "none.filter"), GOLD_INDEX + "/", READS_FA])
     assert rc == 1 and err.startswith("dream_yara_mapper: ")
     rc, err = run([GOLD_INDEX + "/"])
