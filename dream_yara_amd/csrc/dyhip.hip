@@ -135,10 +135,10 @@ struct dy_ctx
     Tuning tune;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    hipStream_t ibfStream = nullptr;   // K1 runs here: the sweep of the NEXT batch overlaps K2..K4 of the current one (dy_map_reads waits for the batch's own sweep)
     hipStream_t side[2] = {};          // K4's list kernels are latency-bound on a handful of waves each: they run side by side
     hipEvent_t evFork = nullptr, evJoin[2] = {};
     dy_map_stats stats = {};
-    bool ibfTimingPending = false;
     // workspaces (grow-only, reused across batches)
     DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
@@ -256,6 +256,8 @@ struct dy_reads
     u32 maskW = 0;       // words per read currently held in masks (0 = none)
     bool recycle = false; // buffers came from / go back to the context's spare pool (batches built per step by dy_reads_from_device)
     u32 maskBins = 0;
+    hipEvent_t evK1[2] = {nullptr, nullptr};   // begin / end of the last dy_ibf_query on these reads (on the context's sweep stream)
+    bool k1Pending = false;                    // the masks are being written by a sweep that nobody has waited for yet
     DevBuf orig;          // dy_reads_from_device_paired: arrival index of every read (the batch is re-ordered to [first mates | second mates])
     bool pairLayout = false;
 };
@@ -359,6 +361,21 @@ static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & r
                        ctx->itemBin.as<u16>(), S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), slab, stride);
 }
 
+// The bin masks of `reads` may still be in the making on the sweep stream: the main stream waits for them (device side, no host stall).
+static void waitForMasks(dy_ctx * ctx, dy_reads * reads)
+{
+    if (reads->k1Pending) HIP_CHECK(hipStreamWaitEvent(ctx->stream, reads->evK1[1], 0));
+}
+// ... and once the main stream has been synchronised behind that wait, the sweep's duration can be read
+static void collectSweepTime(dy_ctx * ctx, dy_reads * reads)
+{
+    if (!reads->k1Pending) return;
+    float ms = 0;
+    HIP_CHECK(hipEventSynchronize(reads->evK1[1]));
+    HIP_CHECK(hipEventElapsedTime(&ms, reads->evK1[0], reads->evK1[1]));
+    ctx->stats.ms_ibf = ms; reads->k1Pending = false;
+}
+
 // Work list (bin-major): (read,bin) items of the masks on `reads` -> ctx->itemRead / itemBin / binStart (+ the local sortedBins() rank).
 static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
 {
@@ -366,6 +383,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
         const u32 nReads = reads->n, W = (nBins + 63) / 64;
         const u32 nWaves = (nReads + 63) / 64;
         const size_t nCells = (size_t)nBins * nWaves;
+        waitForMasks(ctx, reads);
         ctx->waveCounts.reserve((nCells + 1) * 4); ctx->waveOffsets.reserve((nCells + 1) * 4);
         ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
         HIP_CHECK(hipMemsetAsync(ctx->waveCounts.as<u32>() + nCells, 0, 4, st));
@@ -381,7 +399,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
         u32 nItems = 0;
         HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if (ctx->ibfTimingPending) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; ctx->ibfTimingPending = false; }
+        collectSweepTime(ctx, reads);
         ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
         if (nItems)
             hipLaunchKernelGGL(k_items_scatter, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins,
@@ -715,6 +733,7 @@ int dy_ctx_create(int device, dy_ctx ** out)
         std::unique_ptr<dy_ctx> c(new dy_ctx);
         c->device = device;
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&c->ibfStream, hipStreamNonBlocking));
         for (auto & e : c->ev) HIP_CHECK(hipEventCreate(&e));
         for (auto & q : c->side) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
@@ -727,6 +746,7 @@ void dy_ctx_free(dy_ctx * ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->ibfStream) { (void)hipStreamSynchronize(ctx->ibfStream); (void)hipStreamDestroy(ctx->ibfStream); }
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     for (auto & e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto & q : ctx->side) if (q) (void)hipStreamDestroy(q);
@@ -740,6 +760,7 @@ int dy_ctx_sync(dy_ctx * ctx)
 {
     return guarded([&] {
         if (!ctx) throw DyError(DY_EINVAL, "ctx is NULL");
+        HIP_CHECK(hipStreamSynchronize(ctx->ibfStream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
     });
 }
@@ -877,6 +898,7 @@ int dy_kdx_load(dy_ctx * ctx, const char * path, dy_ibf ** out)
 int dy_ibf_add(dy_ibf * f, const uint8_t * seq, uint64_t len, uint32_t bin)
 {
     return guarded([&] {
+        if (f) HIP_CHECK(hipStreamSynchronize(f->ctx->ibfStream));      // no sweep may be reading the filter
         if (!f || (!seq && len)) throw DyError(DY_EINVAL, "dy_ibf_add: NULL argument");
         if (bin >= f->g.nBins) throw DyError(DY_EINVAL, "dy_ibf_add: bin out of range");
         if (len < f->g.kmerSize) return;                        // reference src/d_bloom_filter.h:142-143
@@ -896,6 +918,7 @@ int dy_ibf_add(dy_ibf * f, const uint8_t * seq, uint64_t len, uint32_t bin)
 int dy_ibf_clear_bins(dy_ibf * f, const uint32_t * bins, uint32_t n_bins)
 {
     return guarded([&] {
+        if (f) HIP_CHECK(hipStreamSynchronize(f->ctx->ibfStream));      // no sweep may be reading the filter
         if (!f || (!bins && n_bins)) throw DyError(DY_EINVAL, "dy_ibf_clear_bins: NULL argument");
         std::vector<u64> mask(f->g.W, 0);
         for (u32 i = 0; i < n_bins; ++i)
@@ -918,6 +941,7 @@ int dy_ibf_clear_bins(dy_ibf * f, const uint32_t * bins, uint32_t n_bins)
 int dy_ibf_save(dy_ibf * f, const char * path)
 {
     return guarded([&] {
+        if (f) HIP_CHECK(hipStreamSynchronize(f->ctx->ibfStream));      // no sweep may be reading the filter
         if (!f || !path) throw DyError(DY_EINVAL, "dy_ibf_save: NULL argument");
         HIP_CHECK(hipSetDevice(f->ctx->device));
         std::vector<u64> host(f->nWords);
@@ -935,6 +959,7 @@ int dy_ibf_save(dy_ibf * f, const char * path)
 int dy_ibf_read_words(dy_ibf * f, uint64_t first_word, uint64_t n_words, uint64_t * words_host)
 {
     return guarded([&] {
+        if (f) HIP_CHECK(hipStreamSynchronize(f->ctx->ibfStream));      // no sweep may be reading the filter
         if (!f || (!words_host && n_words)) throw DyError(DY_EINVAL, "dy_ibf_read_words: NULL argument");
         if (first_word > f->nWords || n_words > f->nWords - first_word) throw DyError(DY_EINVAL, "dy_ibf_read_words: range exceeds the filter");
         if (!n_words) return;
@@ -959,7 +984,7 @@ int dy_ibf_get_info(const dy_ibf * f, dy_ibf_info * info)
     return DY_OK;
 }
 
-void dy_ibf_free(dy_ibf * f) { if (f) { (void)hipSetDevice(f->ctx->device); delete f; } }
+void dy_ibf_free(dy_ibf * f) { if (f) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->ibfStream); delete f; } }
 
 uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len)
 {
@@ -1038,6 +1063,8 @@ void dy_reads_free(dy_reads * r)
 {
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
+    if (r->k1Pending) (void)hipEventSynchronize(r->evK1[1]);      // a sweep nobody waited for still writes the masks
+    for (auto & e : r->evK1) if (e) (void)hipEventDestroy(e);
     if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); giveBuffer(r->ctx, r->orig); }
     delete r;
 }
@@ -1053,9 +1080,17 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         if (reads->recycle && !reads->masks.p) takeBuffer(ctx, reads->masks, (size_t)reads->n * W * 8 + 8);
         else reads->masks.reserve((size_t)reads->n * W * 8 + 8);
         reads->maskW = W; reads->maskBins = f->g.nBins;
+        // The sweep runs on the context's second stream: a caller that queues the sweep of its NEXT batch before mapping the current one
+        // gets the two overlapped (dy_map_reads makes the main stream wait for the batch's own sweep).  Everything this call reads was
+        // put in place by synchronous calls (dy_reads_upload, dy_ibf_load / add), so no wait is needed here — except for a mapping that
+        // may still be reading the previous masks of the SAME reads object on the main stream.
+        hipStream_t sq = ctx->ibfStream;
+        for (auto & e : reads->evK1) if (!e) HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(ctx->evFork, ctx->stream));
+        HIP_CHECK(hipStreamWaitEvent(sq, ctx->evFork, 0));
         if (reads->n)
         {
-            HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+            HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
             const bool longReads = reads->maxLen >= 127 + f->g.kmerSize;
             const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
             u32 gShift = 0;
@@ -1076,16 +1111,16 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
             if (kernel == 1 || kernel == 2)
             {
                 const u32 slack = ibfSlack(f, nKmax, threshold);                // (the fill estimate may use the stream: the timed region starts behind it)
-                HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+                HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
                 const size_t perWave = kernel == 1 ? lazyWave : eagerWave;
                 const u32 wavesPerBlock = perWave * 4 <= 32 * 1024 ? 4 : perWave * 2 <= 32 * 1024 ? 2 : 1;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
                 ctx->stats.ibf_kernel = kernel == 1 ? 4 : 5; ctx->stats.ibf_slack = slack;
                 if (kernel == 1)
-                    hipLaunchKernelGGL(k_ibf_query_lazy, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                    hipLaunchKernelGGL(k_ibf_query_lazy, grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, slack);
                 else
-                    hipLaunchKernelGGL(k_ibf_query_eager2, grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                    hipLaunchKernelGGL(k_ibf_query_eager2, grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, listCap);
             }
             else if (W == 1 || ctx->tune.ibfNarrow)
@@ -1095,21 +1130,21 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 if (W == 1 && nKmax > 64 && nKmax <= 127 && !ctx->tune.ibfFullTail)
                 {
                     const u32 slack = ibfSlack(f, nKmax, threshold);
-                    HIP_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+                    HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
                     ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack;
-                    hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                    hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>(), slack);
                 }
                 else if (!longReads)
                 {
                     ctx->stats.ibf_kernel = 2;
-                    hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                    hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
                 }
                 else
                 {
                     ctx->stats.ibf_kernel = 3;
-                    hipLaunchKernelGGL(k_ibf_query<14>, grid, block, 0, ctx->stream, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
+                    hipLaunchKernelGGL(k_ibf_query<14>, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
                                        reads->n, (u32)threshold, reads->masks.as<u64>());
                 }
             }
@@ -1127,7 +1162,7 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 const size_t perWave = ((size_t)fixedWords + (size_t)cacheKmers * G) * 8;
                 const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
                 const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-#define DY_LAUNCH_WIDE(NPV, SP) hipLaunchKernelGGL((k_ibf_query_wide<NPV, SP>), grid, block, perWave * wavesPerBlock, ctx->stream, f->words.as<u64>(), f->g, \
+#define DY_LAUNCH_WIDE(NPV, SP) hipLaunchKernelGGL((k_ibf_query_wide<NPV, SP>), grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, \
                                    reads->seqs.as<u8>(), reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots, sparseCap)
                 if (nK <= 127) { if (sparseCap) DY_LAUNCH_WIDE(7, true); else DY_LAUNCH_WIDE(7, false); }
                 else if (nK <= 255) { if (sparseCap) DY_LAUNCH_WIDE(8, true); else DY_LAUNCH_WIDE(8, false); }
@@ -1135,15 +1170,16 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
 #undef DY_LAUNCH_WIDE
             }
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
+            HIP_CHECK(hipEventRecord(reads->evK1[1], sq));
         }
         if (bin_masks_host)
         {
-            if (reads->n) HIP_CHECK(hipMemcpyAsync(bin_masks_host, reads->masks.p, (size_t)reads->n * W * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if (reads->n) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.ms_ibf = ms; }
+            if (reads->n) HIP_CHECK(hipMemcpyAsync(bin_masks_host, reads->masks.p, (size_t)reads->n * W * 8, hipMemcpyDeviceToHost, sq));
+            HIP_CHECK(hipStreamSynchronize(sq));
+            if (reads->n) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, reads->evK1[0], reads->evK1[1])); ctx->stats.ms_ibf = ms; }
+            reads->k1Pending = false;
         }
-        else if (reads->n) ctx->ibfTimingPending = true;
+        else if (reads->n) reads->k1Pending = true;
     });
 }
 
@@ -1375,6 +1411,7 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
             throw DyError(DY_EINVAL, "dy_ibf_query must run on these reads first (with a filter of the index's bin count)");
         const bool paired = p->paired != 0;
         if (paired && (nReads & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
+        waitForMasks(ctx, reads);
         if (paired && nReads)
             hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(nReads / 2) * W + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nReads / 2, W);
 
@@ -1519,6 +1556,7 @@ int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const 
         const u64 total = (u64)n_ranks * n;
         if (total + 1 > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "ranks x reads too large for one plan");
         if (paired && (n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
+        waitForMasks(ctx, const_cast<dy_reads *>(reads));
         // the four sequences of a pair vote together (reference src/d_mapper.h:350-358): both mates go wherever either is selected
         if (paired && n) hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(n / 2) * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), n / 2, W);
         ctx->planReads = nullptr;
@@ -1541,6 +1579,7 @@ int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const 
             n_reads_to[d] = (u32)(tot[d + 1] - tot[d]);
             n_bases_to[d] = tot[n_ranks + 1 + d + 1] - tot[n_ranks + 1 + d];
         }
+        collectSweepTime(ctx, const_cast<dy_reads *>(reads));
         ctx->planReads = reads; ctx->planRanks = n_ranks; ctx->planTotalReads = tot[n_ranks]; ctx->planTotalBases = tot[2 * n_ranks + 1];
     });
 }
