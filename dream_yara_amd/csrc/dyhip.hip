@@ -1097,10 +1097,10 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
             while ((1u << gShift) < W && gShift < 4) ++gShift;
             const u32 G = 1u << gShift;
             // LDS per wave of the two sweeps for W > 1 (see ibf_kernels.h)
-            const size_t hs = ((size_t)nKmax + 63) & ~(size_t)63;
-            const size_t lazyWave = (2 * hs + 128 + (size_t)nKmax * G + 49 * G) * 8;
-            const u32 listCap = 256;
-            const size_t eagerWave = (3 * hs + 33 * G + listCap + listCap / 4) * 8;
+            const size_t hs = ((size_t)nKmax + 31) & ~(size_t)31;
+            const size_t lazyWave = (2 * hs + 128 + (size_t)nKmax * G + 33 * G) * 8;
+            const u32 listCap = 384;                            // surviving bits of a strand: one per k-mer of the read's own bin + ~0.5 false ones per k-mer
+            const size_t eagerWave = (hs + 128 + 17 * G + 1 + (listCap + 1) / 2) * 8;
             u32 kernel = 3;
             if (W > 1 && !ctx->tune.ibfNarrow && nKmax >= 1 && nKmax <= 255)
             {

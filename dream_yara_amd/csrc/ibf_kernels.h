@@ -706,12 +706,15 @@ __global__ __launch_bounds__(256) void k_ibf_query_wide(const u64 * __restrict__
 //   150 bp / threshold 7: 532 + ~7 positions per read instead of 798 (k_ibf_query_wide: ~1330 requests).
 __device__ __forceinline__ u32 ldsByteGet(const u32 * __restrict__ c, u32 idx) { return (c[idx >> 2] >> (8 * (idx & 3))) & 0xffu; }
 __device__ __forceinline__ void ldsByteInc(u32 * __restrict__ c, u32 idx) { atomicAdd(&c[idx >> 2], 1u << (8 * (idx & 3))); }
+// 16-bit counters, two to an LDS word (counts stay below 256: no carry between the halves); the increment returns the old value
+__device__ __forceinline__ u32 ldsU16Inc(u32 * __restrict__ c, u32 idx) { const u32 sh = (idx & 1) * 16; return (atomicAdd(&c[idx >> 1], 1u << sh) >> sh) & 0xFFFFu; }
+__device__ __forceinline__ u32 ldsU16Get(const u32 * __restrict__ c, u32 idx) { return (c[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu; }
 // every set bit of `bits` (a word of bins [binBase, binBase + 64)) bumps its bin's counter; the bump that reaches `bar` marks the bin
 __device__ __forceinline__ void countBitsMark(u32 * __restrict__ counters, u64 * __restrict__ suspectWord, u32 binBase, u64 bits, u32 bar)
 {
     u32 lo = (u32)bits, hi = (u32)(bits >> 32);
-    while (lo) { const u32 b = (u32)__ffs((int)lo) - 1; lo &= lo - 1; if (atomicAdd(&counters[binBase + b], 1u) + 1 == bar) atomicOr((unsigned long long *)suspectWord, 1ull << b); }
-    while (hi) { const u32 b = (u32)__ffs((int)hi) + 31; hi &= hi - 1; if (atomicAdd(&counters[binBase + b], 1u) + 1 == bar) atomicOr((unsigned long long *)suspectWord, 1ull << b); }
+    while (lo) { const u32 b = (u32)__ffs((int)lo) - 1; lo &= lo - 1; if (ldsU16Inc(counters, binBase + b) + 1 == bar) atomicOr((unsigned long long *)suspectWord, 1ull << b); }
+    while (hi) { const u32 b = (u32)__ffs((int)hi) + 31; hi &= hi - 1; if (ldsU16Inc(counters, binBase + b) + 1 == bar) atomicOr((unsigned long long *)suspectWord, 1ull << b); }
 }
 __device__ __forceinline__ void countBitsBytes(u32 * __restrict__ counters, u32 binBase, u64 bits)
 {
@@ -743,17 +746,17 @@ __global__ __launch_bounds__(256) void k_ibf_query_lazy(const u64 * __restrict__
     }
     const u64 kMask = (1ull << k) - 1;
     const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
-    const u32 hashSlots = (nKcap + 63) & ~63u;
-    // LDS per wave: k-mer hashes | positions of hash function 0 | positions of the round's window under two further hash functions |
-    // hash-0 words w0c[kmer * G + word] | cnt0: u32 per (word, bin), hash-0 hits among the k-mers of phase A | exc, seen: bytes per
-    // (word, bin), exact hits among the verified carriers / verified carriers of phase A | suspect mask per word
-    const size_t perWave = 2 * (size_t)hashSlots + 128 + (size_t)nKcap * G + 32 * G + 16 * G + G;
+    const u32 hashSlots = (nKcap + 31) & ~31u;
+    // LDS per wave (it decides the waves per CU): k-mer hashes | positions of hash function 0 | positions of the round's window under
+    // two further hash functions | hash-0 words w0c[kmer * G + word] | cnt0: u16 per (word, bin), hash-0 hits among the k-mers of phase A |
+    // exc, seen: bytes per (word, bin), exact hits among the verified carriers / verified carriers of phase A | suspect mask per word
+    const size_t perWave = 2 * (size_t)hashSlots + 128 + (size_t)nKcap * G + 16 * G + 16 * G + G;
     u64 * myHash = ldsLazy + (size_t)wave * perWave;
     u64 * myPos0 = myHash + hashSlots;
     u64 * myPosX = myPos0 + hashSlots;                // [2][64]
     u64 * w0c = myPosX + 128;
-    u32 * cnt0 = (u32 *)(w0c + (size_t)nKcap * G);    // 64 G counters
-    u32 * exc = cnt0 + 64 * G;                        // 16 G words of 4 byte counters
+    u32 * cnt0 = (u32 *)(w0c + (size_t)nKcap * G);    // 64 G 16-bit counters = 32 G words
+    u32 * exc = cnt0 + 32 * G;                        // 16 G words of 4 byte counters
     u32 * seen = exc + 16 * G;
     u64 * susp = (u64 *)(seen + 16 * G);              // G words
 
@@ -771,10 +774,9 @@ __global__ __launch_bounds__(256) void k_ibf_query_lazy(const u64 * __restrict__
             for (u32 h0 = 0; h0 < nKmers; h0 += 64)
             {
                 const u64 h = laneKmerHash(seq, len, strand, h0, lane, k, kMask, firstIsN);
-                myHash[h0 + lane] = h;
-                myPos0[h0 + lane] = ibfWordIndex(g, h, 0);
+                if (h0 + lane < nKmers) { myHash[h0 + lane] = h; myPos0[h0 + lane] = ibfWordIndex(g, h, 0); }
             }
-            for (u32 i = lane; i < (64 + 32) * G + 2 * G; i += 64) cnt0[i] = 0;      // cnt0, exc, seen, susp are contiguous
+            for (u32 i = lane; i < (32 + 32) * G + 2 * G; i += 64) cnt0[i] = 0;      // cnt0, exc, seen, susp are contiguous
             __builtin_amdgcn_wave_barrier();
             // ---- phase A
             // first stop where the false bins are expected to have died (slack = false hits a bin may collect by then), then every 8 k-mers
@@ -811,7 +813,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_lazy(const u64 * __restrict__
                 for (u64 todo = susp[wl]; todo; todo &= todo - 1)
                 {
                     const u32 b = (u32)__ffsll((long long)todo) - 1;
-                    const u32 c = cnt0[wl * 64 + b];
+                    const u32 c = ldsU16Get(cnt0, wl * 64 + b);
                     if (c + rest >= threshold) alive |= 1ull << b;
                     if (c >= threshold) strong |= 1ull << b;
                 }
@@ -910,7 +912,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_lazy(const u64 * __restrict__
                     const u32 b = (u32)__ffsll((long long)todo) - 1;
                     const u32 e = ldsByteGet(exc, wl * 64 + b);
                     if (e >= threshold) { selW |= 1ull << b; und &= ~(1ull << b); }
-                    else if (e + (cnt0[wl * 64 + b] - ldsByteGet(seen, wl * 64 + b)) + unlooked < threshold) und &= ~(1ull << b);
+                    else if (e + (ldsU16Get(cnt0, wl * 64 + b) - ldsByteGet(seen, wl * 64 + b)) + unlooked < threshold) und &= ~(1ull << b);
                 }
             }
         }
@@ -918,8 +920,8 @@ __global__ __launch_bounds__(256) void k_ibf_query_lazy(const u64 * __restrict__
     }
 }
 
-// see the comment above k_ibf_query_lazy.  LDS per wave: hashes | positions under hash functions 0 and 1 | u32 counters | suspect
-// masks | list of the non-zero AND-ed words: (k-mer << 4 | word) keys + values.
+// see the comment above k_ibf_query_lazy.  LDS per wave (kept small: it decides the waves per CU): k-mer hashes | positions of a 64-k-mer
+// chunk under hash functions 0 and 1 | 16-bit counters | suspect masks | list of the surviving bits as (k-mer << 10 | word << 6 | bit).
 __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict__ words, IbfGeom g,
                                                           const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
                                                           u32 threshold, u64 * __restrict__ masks, u32 gShift, u32 nKcap, u32 listCap)
@@ -945,15 +947,14 @@ __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict
     }
     const u64 kMask = (1ull << k) - 1;
     const u32 G = 1u << gShift, slots = 64u >> gShift, slot = lane >> gShift, wl = lane & (G - 1);
-    const u32 hashSlots = (nKcap + 63) & ~63u;
-    const size_t perWave = 3 * (size_t)hashSlots + 32 * G + G + listCap + listCap / 4;
+    const u32 hashSlots = (nKcap + 31) & ~31u;
+    const size_t perWave = (size_t)hashSlots + 128 + 16 * G + G + 1 + (listCap + 1) / 2;
     u64 * myHash = ldsEager + (size_t)wave * perWave;
-    u64 * myPos0 = myHash + hashSlots;
-    u64 * myPos1 = myPos0 + hashSlots;
-    u32 * cnt = (u32 *)(myPos1 + hashSlots);          // 64 G counters: k-mers whose hash-0 AND hash-1 words both carry the bin
-    u64 * susp = (u64 *)(cnt + 64 * G);               // G words
-    u64 * listVal = susp + G;                         // listCap AND-ed words
-    u16 * listKey = (u16 *)(listVal + listCap);       // listCap keys: k-mer << 4 | word
+    u64 * myPos = myHash + hashSlots;                 // [2][64]: the current chunk under hash functions 0 and 1
+    u32 * cnt = (u32 *)(myPos + 128);                 // 64 G 16-bit counters: k-mers whose hash-0 AND hash-1 words both carry the bin
+    u64 * susp = (u64 *)(cnt + 32 * G);               // G words
+    u32 * listCount = (u32 *)(susp + G);              // entries appended so far (may run past listCap: the excess is dropped and the list void)
+    u32 * list = listCount + 2;
     const u32 stage1 = g.nHashes >= 2 ? 2 : 1;
 
     for (u32 w0 = 0; w0 < g.W; w0 += G)
@@ -967,45 +968,49 @@ __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict
         {
             const bool firstIsN = strandCode(seq, len, 0, strand) > 3;
             __builtin_amdgcn_wave_barrier();
-            for (u32 h0 = 0; h0 < nKmers; h0 += 64)
+            for (u32 i = lane; i < 32 * G + 2 * G + 2; i += 64) cnt[i] = 0;           // cnt, susp, listCount are contiguous
+            // ---- stage 1: every k-mer, hash functions 0 and 1 together; a chunk of 64 k-mers at a time gets its positions, lane = k-mer
+            for (u32 c0 = 0; c0 < nKmers; c0 += 64)
             {
-                const u64 h = laneKmerHash(seq, len, strand, h0, lane, k, kMask, firstIsN);
-                myHash[h0 + lane] = h;
-                myPos0[h0 + lane] = ibfWordIndex(g, h, 0);
-                if (stage1 == 2) myPos1[h0 + lane] = ibfWordIndex(g, h, 1);
-            }
-            for (u32 i = lane; i < 64 * G + 2 * G; i += 64) cnt[i] = 0;       // cnt and susp are contiguous
-            __builtin_amdgcn_wave_barrier();
-            // ---- stage 1: every k-mer, hash functions 0 and 1 together
-            u32 nList = 0;
-            bool overflow = false;
-            for (u32 kb = 0; kb < nKmers; kb += U * slots)
-            {
-                u64 a[U], b1[U];
-#pragma unroll
-                for (u32 u = 0; u < U; ++u)
+                __builtin_amdgcn_wave_barrier();
                 {
-                    const u32 kk = kb + u * slots + slot;
-                    const bool valid = kk < nKmers && wOk;
-                    a[u] = valid ? words[myPos0[kk] + w] : 0;
-                    b1[u] = (valid && stage1 == 2) ? words[myPos1[kk] + w] : ~0ull;
-                }
-#pragma unroll
-                for (u32 u = 0; u < U; ++u)
-                {
-                    const u32 kk = kb + u * slots + slot;
-                    const u64 v = a[u] & b1[u] & binMask;
-                    countBitsMark(cnt, susp + wl, wl * 64, v, threshold);
-                    const u64 have = ballot64(v != 0);
-                    if (have)
+                    const u64 h = laneKmerHash(seq, len, strand, c0, lane, k, kMask, firstIsN);
+                    if (c0 + lane < nKmers)
                     {
-                        const u32 pos = nList + (u32)__popcll(have & ((1ull << lane) - 1));
-                        if (v != 0 && pos < listCap) { listVal[pos] = v; listKey[pos] = (u16)((kk << 4) | wl); }
-                        nList += (u32)__popcll(have);
+                        myHash[c0 + lane] = h;
+                        myPos[lane] = ibfWordIndex(g, h, 0);
+                        if (stage1 == 2) myPos[64 + lane] = ibfWordIndex(g, h, 1);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const u32 inChunk = min(64u, nKmers - c0);
+                for (u32 kb = 0; kb < inChunk; kb += U * slots)
+                {
+                    u64 a[U], b1[U];
+#pragma unroll
+                    for (u32 u = 0; u < U; ++u)
+                    {
+                        const u32 kl = kb + u * slots + slot;
+                        const bool valid = kl < inChunk && wOk;
+                        a[u] = valid ? words[myPos[kl] + w] : 0;
+                        b1[u] = (valid && stage1 == 2) ? words[myPos[64 + kl] + w] : ~0ull;
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < U; ++u)
+                    {
+                        const u32 kk = c0 + kb + u * slots + slot;
+                        u64 v = a[u] & b1[u] & binMask;
+                        while (v)
+                        {
+                            const u32 b = (u32)__ffsll((long long)v) - 1;
+                            v &= v - 1;
+                            if (ldsU16Inc(cnt, wl * 64 + b) + 1 == threshold) atomicOr((unsigned long long *)(susp + wl), 1ull << b);
+                            const u32 pos = atomicAdd(listCount, 1u);
+                            if (pos < listCap) list[pos] = (kk << 10) | (wl << 6) | b;
+                        }
                     }
                 }
             }
-            if (nList > listCap) { overflow = true; nList = listCap; }
             __builtin_amdgcn_wave_barrier();
             if (ballot64(susp[wl] != 0) == 0) continue;                      // no bin reaches the threshold even on two hash functions
             if (g.nHashes <= stage1)
@@ -1014,6 +1019,8 @@ __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict
                 continue;
             }
             // ---- stage 2: the suspects against the remaining hash functions, one suspect at a time (there is normally one)
+            const u32 nList = *listCount;
+            const bool overflow = nList > listCap;
             for (u32 ow = 0; ow < G; ++ow)
             {
                 u64 todo = susp[ow];
@@ -1021,15 +1028,16 @@ __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict
                 {
                     const u32 b = (u32)__ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    const u32 carriers = cnt[ow * 64 + b];
+                    const u32 carriers = ldsU16Get(cnt, ow * 64 + b);
+                    const u32 want = (ow << 6) | b;
                     u32 exact = 0, seenC = 0;
                     bool decided = false, accepted = false;
                     if (!overflow)
                         for (u32 l0 = 0; l0 < nList && !decided; l0 += 64)
                         {
                             const u32 li = l0 + lane;
-                            bool car = false; u32 key = 0;
-                            if (li < nList) { key = listKey[li]; car = (key & 15) == ow && ((listVal[li] >> b) & 1); }
+                            bool car = false; u32 e = 0;
+                            if (li < nList) { e = list[li]; car = (e & 1023u) == want; }
                             u64 pending = ballot64(car);
                             while (pending && !decided)
                             {
@@ -1038,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict
                                 bool hit = act;
                                 if (act)
                                 {
-                                    const u64 h = myHash[key >> 4];
+                                    const u64 h = myHash[e >> 10];
                                     for (u32 hf = stage1; hf < g.nHashes; ++hf) hit = hit && ((words[ibfWordIndex(g, h, hf) + w0 + ow] >> b) & 1);
                                 }
                                 const u64 actMask = ballot64(act);
@@ -1050,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_eager2(const u64 * __restrict
                             }
                         }
                     else
-                    {   // the list overflowed (pathological: hundreds of surviving words): plain sweep over every k-mer for this bin
+                    {   // the list overflowed (pathological: hundreds of surviving bits): plain sweep over every k-mer for this bin
                         for (u32 kb = 0; kb < nKmers && !decided; kb += 64)
                         {
                             const u32 kk = kb + lane;
