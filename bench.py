@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--paired", action="store_true", help="paired-end batch: reads/2 pairs of 2 x L bp, insert N(400, 40) (BASELINE configs[3]); not the default metric")
     ap.add_argument("--shard", default="both", choices=["both", "reads", "bins"], help="what is partitioned across ranks (see module docstring); at N = 1 'both' means reads")
     ap.add_argument("--bins-leg-timeout", type=float, default=300.0, help="seconds after which the bins-sharded leg of --shard both is given up (the line is printed without it)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dy_ctx_set_tuning knob for experiments (result-identical code paths; see include/dyhip.h)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -166,6 +167,9 @@ def main():
     genomes, idx_dir = build_inputs(wl, work_dir, rank, world, barrier)
 
     ctx = dy.Context(local_rank)
+    for kv in args.tune:
+        key, val = kv.split("=", 1)
+        ctx.set_tuning(key, int(val))
     t0 = time.time()
     n_bits = (wl["ibf_gib"] << 33) if wl["ibf_gib"] else (1 << 28)
     ibf = dy.Ibf.create(ctx, wl["bins"], wl["h"], wl["k"], n_bits + 256)

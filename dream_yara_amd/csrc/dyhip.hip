@@ -127,6 +127,8 @@ struct Tuning
     u64 ibfKernel = 0;          // sweep for W > 1 and reads of at most 255 k-mers: 0 = by expected false candidates, 1 = k_ibf_query_lazy, 2 = k_ibf_query_eager2, 3 = k_ibf_query_wide
     u64 ibfSlack = 0;           // first check of the sweeps = nK - threshold + slack k-mers (0 = derived from the filter's fill)
     u64 poolCap = 0;            // initial capacity of the raw-match pool (0 = 2 x items); it grows on overflow either way
+    u64 dpSmallBlocks = 4096;   // grid of the thread-level aggregation kernels (k_finalize_small, k_pe_*): list-driven, grid-stride
+    u64 dpAlignBlocks = 8192;   // grid of k_align_single
 };
 
 struct dy_ctx
@@ -563,15 +565,15 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             const u32 traceRows = std::min<u32>(reads->maxLen, THREAD_DP_MAX_LEN) + 1;
             const u32 dpThreads = (size_t)traceRows * 64 * (narrowBand ? 4 : 8) > 60 * 1024 ? 32 : 64;      // stay within 64 KB of LDS per block
             const size_t traceLds = (size_t)traceRows * dpThreads * (narrowBand ? 4 : 8);
-            if (narrowBand) hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
-            else hipLaunchKernelGGL((k_finalize_small<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
+            if (narrowBand) hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
+            else hipLaunchKernelGGL((k_finalize_small<7, u64>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
             hipLaunchKernelGGL(k_finalize_t<BlockGroup>, dim3(hugeBlocks), dim3(1024), 0, ctx->side[0], fa, blockMin + 1, 0xFFFFFFFFu, finWaves);
             hipLaunchKernelGGL(k_finalize_t<WaveGroup>, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa, 0u, blockMin, 0u);
             HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
             HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
             hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount);
-            if (narrowBand) hipLaunchKernelGGL((k_align_single<3, u32>), dim3(8192), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
-            else hipLaunchKernelGGL((k_align_single<7, u64>), dim3(8192), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
+            if (narrowBand) hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
+            else hipLaunchKernelGGL((k_align_single<7, u64>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
         }
@@ -659,13 +661,13 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                 HIP_CHECK(hipStreamWaitEvent(ctx->side[1], ctx->evFork, 0));
                 if (narrowBand)
                 {
-                    hipLaunchKernelGGL((k_pe_align_single<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
-                    hipLaunchKernelGGL((k_pe_finalize_small<3, u32>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[1], fa, V, ctx->peMStart.as<u32>(), ctx->smallList.as<u32>(), peSmallCount);
+                    hipLaunchKernelGGL((k_pe_align_single<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+                    hipLaunchKernelGGL((k_pe_finalize_small<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[1], fa, V, ctx->peMStart.as<u32>(), ctx->smallList.as<u32>(), peSmallCount);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((k_pe_align_single<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[0], fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
-                    hipLaunchKernelGGL((k_pe_finalize_small<7, u64>), dim3(4096), dim3(dpThreads), traceLds, ctx->side[1], fa, V, ctx->peMStart.as<u32>(), ctx->smallList.as<u32>(), peSmallCount);
+                    hipLaunchKernelGGL((k_pe_align_single<7, u64>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, V, ctx->peMStart.as<u32>(), ctx->alignList.as<u32>(), peAlignCount);
+                    hipLaunchKernelGGL((k_pe_finalize_small<7, u64>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[1], fa, V, ctx->peMStart.as<u32>(), ctx->smallList.as<u32>(), peSmallCount);
                 }
                 HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
                 HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
@@ -778,7 +780,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
             {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255},
-            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull},
+            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536},
         };
         for (auto & k : keys)
             if (!strcmp(k.name, key))

@@ -124,6 +124,28 @@ int dyo_align_match(const u8 * contig, int n, const u8 * read, int m, int errors
     return k;
 }
 
+// Seed search of one bin on its own (tests of the search definitions): every occurrence reported for `seed` with at most maxErr
+// errors — Hamming (edit = 0, reference Backtracking<HammingDistance>) or edit distance (edit = 1, -y full) — as (contig, END position
+// in the forward contig, errors) triples.  The end is what the extension anchors on (reference src/mapper_extender.h:263-285).
+// Returns the number of occurrences; at most `cap` are written.
+u64 dyo_seed_occurrences(void * idxv, u32 bin, const u8 * seed, u32 len, u32 maxErr, int edit, u32 * out, u64 cap)
+{
+    DreamIndex & idx = *(DreamIndex *)idxv;
+    const Bin & b = idx.bins[bin];
+    std::vector<Hit> hits;
+    if (edit && maxErr) fmSearchEdit(b.fm, seed, len, maxErr, 0, hits); else fmSearch(b.fm, seed, len, maxErr, 0, hits);
+    u64 n = 0;
+    for (auto & h : hits)
+        for (u32 row = h.lo; row < h.hi; ++row)
+        {
+            u32 contig, x;
+            b.fm.locate(row, contig, x);
+            if (n < cap) { out[3 * n] = contig; out[3 * n + 1] = (u32)(b.contigs.length(contig) - x); out[3 * n + 2] = h.errors; }
+            ++n;
+        }
+    return n;
+}
+
 void * dyo_index_load(const char * dir, u32 nBins)
 {
     try { std::string d(dir); while (d.size() > 1 && d.back() == '/') d.pop_back(); return new DreamIndex(loadDreamIndex(d, nBins)); }

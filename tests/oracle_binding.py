@@ -35,6 +35,8 @@ def lib():
         l.dyo_ibf_build.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, P, P, C.c_uint32]
         l.dyo_index_load.restype = P; l.dyo_index_load.argtypes = [C.c_char_p, C.c_uint32]
         l.dyo_index_free.argtypes = [P]
+        l.dyo_seed_occurrences.restype = C.c_uint64
+        l.dyo_seed_occurrences.argtypes = [P, C.c_uint32, P, C.c_uint32, C.c_uint32, C.c_int, P, C.c_uint64]
         l.dyo_index_build.restype = C.c_int; l.dyo_index_build.argtypes = [C.c_char_p, P, P, C.c_uint32]
         l.dyo_map_batch.restype = P
         l.dyo_map_batch.argtypes = [P, P, P, P, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_uint, C.c_uint]
@@ -117,6 +119,16 @@ class OracleIndex:
         if self.h:
             lib().dyo_index_free(self.h)
             self.h = None
+
+
+def seed_occurrences(index, bin_no, seed, max_err, edit):
+    """(contig, forward END position, errors) of every occurrence the oracle's seed search reports (Hamming or edit distance)."""
+    seed = np.ascontiguousarray(seed, dtype=np.uint8)
+    cap = 1 << 16
+    out = np.zeros((cap, 3), dtype=np.uint32)
+    n = int(lib().dyo_seed_occurrences(index.h, bin_no, seed.ctypes.data, seed.size, max_err, 1 if edit else 0, out.ctypes.data, cap))
+    assert n <= cap
+    return out[:n]
 
 
 def map_batch(index, ibf, codes, offs, error_rate, strata_rate=0.0, sensitivity=1, hits_threshold=300, threads=4,
