@@ -54,6 +54,24 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+# stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to stdout when its first communicator comes up, so
+# file descriptor 1 is pointed at stderr for the run and the line is written to the saved descriptor
+_REAL_STDOUT = None
+
+
+def capture_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (line + "\n").encode()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, data)
+
+
 def build_inputs(wl, work_dir, rank, world, barrier):
     """Setup (untimed): genomes, index files (rank 0 builds, all load), reads. Returns (genomes, index_dir)."""
     from dream_yara_amd import synth
@@ -140,6 +158,7 @@ def main():
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
+    capture_stdout()
 
     from dream_yara_amd.dist import Group, shard_seed, whole_job_rate
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -335,7 +354,7 @@ def main():
             if not done.wait(args.bins_leg_timeout):
                 if rank == 0:
                     line = dict(first["line"]); line["bins_sharded"] = {"error": "no result within %.0f s" % args.bins_leg_timeout}
-                    print(json.dumps(line), flush=True)
+                    emit(json.dumps(line))
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
@@ -368,7 +387,7 @@ def main():
             if diff:
                 base["parity_differs_in"] = diff
             out["cpu_baseline"] = base
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     barrier()
     for r in batches:
         r.close()

@@ -30,19 +30,39 @@ def owner_masks(n_bins, world):
     return m
 
 
-def exchange_bytes(dist, send, send_splits, device):
-    """all-to-all(v) of a uint8 tensor split per destination rank.  Returns (recv tensor on `device`, recv splits)."""
-    world = len(send_splits)
+def exchange_counts(dist, rows, device):
+    """all-to-all of a small int64 matrix: rows[d] = the numbers this rank has for rank d.  Returns what every rank has for this one."""
     backend = dist.get_backend()
     comm_dev = device if backend == "nccl" else "cpu"
-    s = torch.tensor([int(x) for x in send_splits], dtype=torch.int64, device=comm_dev)
-    r = torch.empty(world, dtype=torch.int64, device=comm_dev)
+    s = torch.tensor(np.asarray(rows, dtype=np.int64), dtype=torch.int64, device=comm_dev).contiguous()
+    r = torch.empty_like(s)
     dist.all_to_all_single(r, s)
-    recv_splits = [int(x) for x in r.tolist()]
-    out = torch.empty(sum(recv_splits), dtype=torch.uint8, device=comm_dev)
-    src = send if backend == "nccl" else send.cpu()
-    dist.all_to_all_single(out, src, output_split_sizes=recv_splits, input_split_sizes=[int(x) for x in send_splits])
-    return out.to(device), recv_splits
+    return r.cpu().numpy()
+
+
+def exchange_data(dist, sends, send_splits, recv_splits, device):
+    """Several all-to-all(v)s of uint8 tensors with known receive sizes, queued together and awaited once (the per-collective latency
+    is what a small batch pays; the counts travel in ONE exchange_counts beforehand).  Returns the received tensors on `device`."""
+    backend = dist.get_backend()
+    comm_dev = device if backend == "nccl" else "cpu"
+    outs, works, keep = [], [], []
+    for send, ss, rs in zip(sends, send_splits, recv_splits):
+        out = torch.empty(int(sum(rs)), dtype=torch.uint8, device=comm_dev)
+        src = send if backend == "nccl" else send.cpu()
+        keep.append(src)                                    # a staged copy must outlive its queued collective
+        works.append(dist.all_to_all_single(out, src, output_split_sizes=[int(x) for x in rs], input_split_sizes=[int(x) for x in ss], async_op=True))
+        outs.append(out)
+    for w in works:
+        w.wait()
+    return [o.to(device) for o in outs]
+
+
+def exchange_bytes(dist, send, send_splits, device):
+    """all-to-all(v) of a uint8 tensor split per destination rank.  Returns (recv tensor on `device`, recv splits)."""
+    counts = exchange_counts(dist, [[int(x)] for x in send_splits], device)
+    recv_splits = [int(x) for x in counts[:, 0]]
+    out, = exchange_data(dist, [send], [send_splits], [recv_splits], device)
+    return out, recv_splits
 
 
 def all_reduce_sum(dist, values, device):
@@ -77,10 +97,14 @@ class ShardedMapper:
         ids, lens, masks, seqs = u8(n_tot * 4), u8(n_tot * 4), u8(n_tot * W * 8), u8(b_tot)
         torch.cuda.synchronize()
         dy.shard_pack(ctx, reads, ids.data_ptr(), lens.data_ptr(), masks.data_ptr(), seqs.data_ptr())
-        r_ids, rs = exchange_bytes(self.dist, ids, n_to.astype(np.int64) * 4, dev)
-        r_lens, _ = exchange_bytes(self.dist, lens, n_to.astype(np.int64) * 4, dev)
-        r_masks, _ = exchange_bytes(self.dist, masks, n_to.astype(np.int64) * W * 8, dev)
-        r_seqs, _ = exchange_bytes(self.dist, seqs, b_to.astype(np.int64), dev)
+        # C1: one exchange of (reads, bases) per pair of ranks, then the four buffers together
+        got = exchange_counts(self.dist, np.stack([n_to.astype(np.int64), b_to.astype(np.int64)], axis=1), dev)
+        n_from, b_from = got[:, 0], got[:, 1]
+        r_ids, r_lens, r_masks, r_seqs = exchange_data(
+            self.dist, [ids, lens, masks, seqs],
+            [n_to.astype(np.int64) * 4, n_to.astype(np.int64) * 4, n_to.astype(np.int64) * W * 8, b_to.astype(np.int64)],
+            [n_from * 4, n_from * 4, n_from * W * 8, b_from], dev)
+        rs = [int(x) * 4 for x in n_from]
         torch.cuda.synchronize()
         n_recv = r_ids.numel() // 4
         seg = np.zeros(self.world + 1, np.uint32); seg[1:] = np.cumsum([x // 4 for x in rs])
@@ -91,14 +115,23 @@ class ShardedMapper:
         torch.cuda.synchronize()
         raw_to = dy.raw_pack(ctx, seg, r_ids.data_ptr(), raw.data_ptr())             # C2 pack
         r_items, n_items_in = None, 0
+        items, items_to = None, np.zeros(self.world, np.uint64)
         if paired:
             items = u8(int(loads.sum()) * dy.PE_ITEM_BYTES)
             items_to = dy.pe_items_pack(ctx, seg, r_ids.data_ptr(), items.data_ptr())
-            n_sent = int(items_to.sum())
-            r_items, _ = exchange_bytes(self.dist, items[: n_sent * dy.PE_ITEM_BYTES], items_to.astype(np.int64) * dy.PE_ITEM_BYTES, dev)
-            n_items_in = r_items.numel() // dy.PE_ITEM_BYTES
+            items = items[: int(items_to.sum()) * dy.PE_ITEM_BYTES]
         sub.close()
-        r_raw, _ = exchange_bytes(self.dist, raw, raw_to.astype(np.int64) * dy.RAW_MATCH_BYTES, dev)
+        # C2: one exchange of (raw matches, pairing records) per pair of ranks, then the buffers together
+        got = exchange_counts(self.dist, np.stack([raw_to.astype(np.int64), items_to.astype(np.int64)], axis=1), dev)
+        raw_from, items_from = got[:, 0], got[:, 1]
+        sends, ssp, rsp = [raw], [raw_to.astype(np.int64) * dy.RAW_MATCH_BYTES], [raw_from * dy.RAW_MATCH_BYTES]
+        if paired:
+            sends.append(items); ssp.append(items_to.astype(np.int64) * dy.PE_ITEM_BYTES); rsp.append(items_from * dy.PE_ITEM_BYTES)
+        recv = exchange_data(self.dist, sends, ssp, rsp, dev)
+        r_raw = recv[0]
+        if paired:
+            r_items = recv[1]
+            n_items_in = r_items.numel() // dy.PE_ITEM_BYTES
         g_loads = all_reduce_sum(self.dist, loads, dev)                              # C3
         torch.cuda.synchronize()
         self.last = {"sent_reads": n_tot, "recv_reads": n_recv, "raw_out": n_raw, "raw_in": r_raw.numel() // dy.RAW_MATCH_BYTES,
