@@ -1,7 +1,7 @@
 // Micro-benchmark: the chip's ceiling for random gathers of 8 .. 128 bytes over tables of 64 MiB .. 64 GiB on MI355X — what K1 (the
 // IBF sweep) is bound by.  A request of `width` bytes is served by G adjacent lanes, each loading V x 8 bytes of one aligned
 // group (the production kernels use V = 1: one 64-bit word per lane), every request at an independent pseudo-random position.
-//   hipcc --offload-arch=gfx950 -O3 -o scripts/ubench_gather scripts/ubench_gather.hip && scripts/ubench_gather [max_gib] > profiles/<round>_gather_sweep.jsonl
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/ubench_gather scripts/ubench_gather.hip && scripts/ubench_gather [max_gib [min_mib]] > profiles/<round>_gather_sweep.jsonl
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -58,12 +58,13 @@ template <int G, int V, int ILP> void run(const u64 * t, u64 tableBytes, u64 * o
 int main(int argc, char ** argv)
 {
     const u64 maxGib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 64;
+    const u64 minMib = argc > 2 ? strtoull(argv[2], nullptr, 10) : 64;          // smaller tables: L2- / Infinity-Cache-resident gathers
     u64 * t; u64 * out;
     if (hipMalloc(&t, maxGib << 30) != hipSuccess) { fprintf(stderr, "cannot allocate %llu GiB\n", (unsigned long long)maxGib); return 1; }
     hipMalloc(&out, 8);
     hipMemset(t, 0x5a, maxGib << 30);
     hipDeviceSynchronize();
-    for (u64 mib = 64; mib <= (maxGib << 10); mib *= 4)
+    for (u64 mib = minMib; mib <= (maxGib << 10); mib *= 4)
     {
         const u64 bytes = mib << 20;
         run<1, 1, 4>(t, bytes, out);     //   8 B: one lane, one word (W = 1: 64 bins)
