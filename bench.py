@@ -303,7 +303,7 @@ def main():
         achieved = bytes_per_read * per_batch / k1_s / 1e9 if k1_s > 0 else 0.0
         # HBM traffic of that kernel per launch comes from a committed PMC pass of the same build and workload (rocprofv3 --pmc, separate
         # passes; narrow gathers are accounted at 64 B per request, calibrated on scripts/ubench_gather.hip) — it is NOT measured in this run
-        traffic, traffic_src, secondary = None, None, None
+        traffic, traffic_src, secondary, line_slots = None, None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % args.workload)
         if os.path.exists(pmc_file):
             allk = json.load(open(pmc_file))
@@ -312,6 +312,13 @@ def main():
             if pmc:
                 traffic = (pmc["FETCH_SIZE"] + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
                 traffic_src = "profiles/" + os.path.basename(pmc_file)
+                if "TCC_EA0_RDREQ_sum" in pmc and k1_s > 0:
+                    # every L2 miss, narrow or wide, occupies one 128-B line slot of the memory side (profiles/r02_gather_mix.jsonl: random 8-B
+                    # gathers and a coalesced stream running together add up in 128-B lines; FETCH_SIZE tallies a request at 64 B)
+                    req = pmc["TCC_EA0_RDREQ_sum"] * (per_batch / pmc["SQ_WAVES"] if pmc.get("SQ_WAVES") else 1.0)      # one wavefront per read
+                    line_slots = {"l2_read_requests_per_launch": req, "bytes_at_128B_per_request": req * 128.0,
+                                  "achieved_GBps": req * 128.0 / k1_s / 1e9, "frac_of_hbm_peak": req * 128.0 / k1_s / 1e9 / 8000.0,
+                                  "source": traffic_src + " (requests per read) and this run's launch duration"}
             k2 = next((v for kk, v in allk.items() if "k_seed_search" in kk and "TCC_HIT_sum" in v), None)
             if k2:
                 hit, miss = k2["TCC_HIT_sum"], k2["TCC_MISS_sum"]
@@ -330,11 +337,11 @@ def main():
                        "items_per_read": leg["items_per_read"], "raw_matches_per_read": leg["raw_matches_per_read"],
                        "stage_ms_per_step": leg["stage_ms_per_step"], "device_tables": leg["device_tables"]},
             "roofline": {"kernel": leg["ibf_kernel"], "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_source": traffic_src, "launch_ms": 1e3 * k1_s,
+                         "traffic": traffic, "traffic_source": traffic_src, "line_slots": line_slots, "launch_ms": 1e3 * k1_s,
                          "note": ("algorithmic bytes %d B/read x %d reads per launch; " % (bytes_per_read, per_batch)) +
-                                 "the chip serves 48-60 G random requests/s whatever their width from 8 to 128 B (profiles/r02_gather_ceiling.json) and a hash position of W <= 16 words is one request, "
+                                 "the chip serves 48-60 G random requests/s whatever their width from 8 to 128 B (profiles/r02_gather_ceiling.json: each L2 miss takes one 128-B line slot, 56 G/s x 128 B = 7.2 TB/s) and a hash position of W <= 16 words is one request, "
                                  "so the sweep is bound by the number of (k-mer, hash) positions it touches; it prunes those that cannot change a result (first check at nK - threshold + %d k-mers, from the sampled filter fill); "
-                                 "at W = 1 only 8 of the 64 B a request moves are algorithmic bytes" % leg["ibf_first_check_slack"],
+                                 "at W = 1 only 8 of the 128 B of a line slot are algorithmic bytes" % leg["ibf_first_check_slack"],
                          "secondary": secondary},
         }
         if args.paired:

@@ -55,6 +55,52 @@ template <int G, int V, int ILP> void run(const u64 * t, u64 tableBytes, u64 * o
     hipEventDestroy(a); hipEventDestroy(b);
 }
 
+// What is the ceiling made of?  Gathers of 8 B with S streamed (coalesced, 16 B per lane) bytes per gather read next to them from a
+// second buffer: if a narrow gather only costs a request slot, the stream rides along for free until HBM is full; if every gather
+// moves a whole 128-B line, stream and gathers share the same bytes per second.
+template <int SPG>   // streamed 16-B loads per 4 gathers per lane
+__global__ __launch_bounds__(256) void gatherPlusStream(const u64 * __restrict__ t, u64 groupMask, u64 nReq, const uint4 * __restrict__ stream, u64 streamMask, u64 * out)
+{
+    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x, nT = (u64)gridDim.x * blockDim.x;
+    u64 acc = 0; u64 sp = tid;
+    for (u64 i = tid; i < nReq; i += nT * 4)
+    {
+        u64 v[4]; uint4 w[SPG > 0 ? SPG : 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+            u64 h = (i + (u64)k * nT) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            v[k] = t[h & groupMask];
+        }
+#pragma unroll
+        for (int k = 0; k < SPG; ++k) { w[k] = stream[sp & streamMask]; sp += nT; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += v[k] | 1;
+#pragma unroll
+        for (int k = 0; k < SPG; ++k) acc += w[k].x ^ w[k].w;
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+
+template <int SPG> void runMix(const u64 * t, u64 tableBytes, const uint4 * stream, u64 streamBytes, u64 * out, bool gathers)
+{
+    const u64 nReq = gathers ? 256ull << 20 : 256ull << 20;
+    const int blocks = 256 * 8, threads = 256;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 2; ++rep)
+    {
+        if (rep == 1) hipEventRecord(a);
+        hipLaunchKernelGGL((gatherPlusStream<SPG>), dim3(blocks), dim3(threads), 0, 0, t, gathers ? tableBytes / 8 - 1 : 0ull, nReq, stream, streamBytes / 16 - 1, out);
+    }
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double streamed = (double)nReq / 4 * SPG * 16;
+    printf("{\"mix\": true, \"table_mib\": %llu, \"random_gathers\": %s, \"streamed_bytes_per_gather\": %d, \"ms\": %.3f, \"G_gathers_per_s\": %.2f, \"stream_TB_per_s\": %.3f}\n",
+           (unsigned long long)(tableBytes >> 20), gathers ? "true" : "false (all gathers hit one word)", SPG * 4, ms, nReq / ms / 1e6, streamed / ms / 1e9);
+    fflush(stdout);
+    hipEventDestroy(a); hipEventDestroy(b);
+}
+
 int main(int argc, char ** argv)
 {
     const u64 maxGib = argc > 1 ? strtoull(argv[1], nullptr, 10) : 64;
@@ -64,6 +110,22 @@ int main(int argc, char ** argv)
     hipMalloc(&out, 8);
     hipMemset(t, 0x5a, maxGib << 30);
     hipDeviceSynchronize();
+    if (argc > 3)
+    {   // mix mode: <max_gib> <min_mib> mix — gathers over the first GiB, the stream over the second half of the allocation
+        const u64 tb = 1ull << 30; const uint4 * stream = (const uint4 *)(t + (maxGib << 30) / 16); const u64 sb = (maxGib << 30) / 2;
+        runMix<0>(t, tb, stream, sb, out, true);
+        runMix<1>(t, tb, stream, sb, out, true);
+        runMix<2>(t, tb, stream, sb, out, true);
+        runMix<4>(t, tb, stream, sb, out, true);
+        runMix<8>(t, tb, stream, sb, out, true);
+        runMix<16>(t, tb, stream, sb, out, true);
+        runMix<4>(t, tb, stream, sb, out, false);
+        runMix<8>(t, tb, stream, sb, out, false);
+        runMix<16>(t, tb, stream, sb, out, false);
+        run<32, 1, 4>(t, tb, out);       // 256 B: two lines per request
+        run<16, 2, 4>(t, tb, out);
+        return 0;
+    }
     for (u64 mib = minMib; mib <= (maxGib << 10); mib *= 4)
     {
         const u64 bytes = mib << 20;
