@@ -307,9 +307,24 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
         cw[d] = (idx >= 0 && idx < n) ? ctg[idx] : 5u;
     }
     trace[0] = 0;
+    // The read base and the incoming contig base of a row are loaded TWO rows ahead, as raw bytes: their latency hides behind the rows'
+    // ~250 instructions each.  (One row ahead is not enough: the load counter is in-order, and the wait the compiler places at the loop
+    // head for the loads issued before the loop also covers the load the row has just issued; complementing the byte right behind the
+    // load would make the row wait for it on the spot.)
+    // Both loads are unconditional (clamped index, validity applied at the use): with a conditional load in the loop the compiler's wait
+    // for the bytes loaded before the loop would also cover the byte the row has just asked for.
+    const u8 * rp = strand ? seq + (m - 1) : seq;
+    const int rstep = strand ? -1 : 1;
+    auto rawAt = [&](int row) -> u32 { return rp[(row <= m ? row - 1 : m - 1) * rstep]; };                       // read base of row `row` (1-based)
+    auto incomingAt = [&](int row) -> u32 { const int idx = row + BM - 1 - e; return ctg[idx < 0 ? 0 : (idx < n ? idx : n - 1)]; };
+    auto incomingValid = [&](int row) -> bool { const int idx = row + BM - 1 - e; return idx >= 0 && idx < n; };
+    u32 raw1 = 0, raw2 = 0, inc1 = 5, inc2 = 5;
+    if (m > 0 && n > 0) { raw1 = rawAt(1); inc1 = incomingAt(1); raw2 = rawAt(2); inc2 = incomingAt(2); }
     for (int i = 1; i <= m; ++i)
     {
-        const u32 rc = readBase(seq, readLen, strand, (u32)(i - 1));
+        const u32 rc = (strand && raw1 < 4) ? 3 - raw1 : raw1, incoming = incomingValid(i) ? inc1 : 5u;
+        raw1 = raw2; inc1 = inc2;
+        if (n > 0) { raw2 = rawAt(i + 2); inc2 = incomingAt(i + 2); }
         int cS[BM], cV[BM];
         int leftS = NEG, leftH = NEG;
         TRow row = 0;
@@ -344,8 +359,6 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
             row |= (TRow)tr << (4 * d);
         }
         trace[(size_t)i * traceStride] = row;
-        const int nextIdx = i + BM - 1 - e;
-        const u32 incoming = (nextIdx >= 0 && nextIdx < n) ? ctg[nextIdx] : 5u;
 #pragma unroll
         for (int d = 0; d < BM; ++d) { pS[d] = cS[d]; pV[d] = cV[d]; cw[d] = d + 1 < BM ? cw[d + 1 < BM ? d + 1 : d] : incoming; }
     }
