@@ -129,6 +129,7 @@ struct Tuning
     u64 poolCap = 0;            // initial capacity of the raw-match pool (0 = 2 x items); it grows on overflow either way
     u64 dpSmallBlocks = 4096;   // grid of the thread-level aggregation kernels (k_finalize_small, k_pe_*): list-driven, grid-stride
     u64 dpAlignBlocks = 8192;   // grid of k_align_single
+    u64 itemsSorted = 1;        // work list: 1 = (bin, read) pairs in read order + stable radix sort by bin, 0 = bin-major count matrix + scan + scatter
 };
 
 struct dy_ctx
@@ -383,11 +384,43 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
 {
         hipStream_t st = ctx->stream;
         const u32 nReads = reads->n, W = (nBins + 63) / 64;
+        waitForMasks(ctx, reads);
+        ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
+        u32 nItems = 0;
+        if (ctx->tune.itemsSorted)
+        {   // (bin, read) pairs in read order, stable radix sort by bin (map_kernels.h)
+            const u64 nWords = (u64)nReads * W;
+            ctx->waveCounts.reserve((size_t)(nReads + 1) * 4); ctx->waveOffsets.reserve((size_t)(nReads + 1) * 4);
+            HIP_CHECK(hipMemsetAsync(ctx->waveCounts.p, 0, (size_t)(nReads + 1) * 4, st));
+            if (nWords) hipLaunchKernelGGL(k_items_word_count, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, ctx->waveCounts.as<u32>());
+            size_t tmpBytes = 0;
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nReads + 1), st));
+            ctx->scanTmp.reserve(tmpBytes + 64);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nReads + 1), st));
+            HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nReads, 4, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            collectSweepTime(ctx, reads);
+            ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
+            ctx->itemKeys.reserve((size_t)nItems * 4 + 64); ctx->itemPerm.reserve((size_t)nItems * 4 + 64);      // unsorted keys / values (free until the K3 work order)
+            if (nItems)
+            {
+                hipLaunchKernelGGL(k_items_emit, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, nBins, ctx->waveOffsets.as<u32>(),
+                                   ctx->itemKeys.as<u16>(), ctx->itemPerm.as<u32>());
+                int bits = 1; while ((1u << bits) < nBins) ++bits;
+                size_t sortBytes = 0;
+                HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, ctx->itemKeys.as<u16>(), ctx->itemBin.as<u16>(), ctx->itemPerm.as<u32>(), ctx->itemRead.as<u32>(),
+                                                             (int)nItems, 0, bits, st));
+                ctx->scanTmp.reserve(sortBytes + 64);
+                HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ctx->scanTmp.p, sortBytes, ctx->itemKeys.as<u16>(), ctx->itemBin.as<u16>(), ctx->itemPerm.as<u32>(), ctx->itemRead.as<u32>(),
+                                                             (int)nItems, 0, bits, st));
+            }
+            hipLaunchKernelGGL(k_items_bin_bounds, dim3((nBins + 1 + 255) / 256), dim3(256), 0, st, ctx->itemBin.as<u16>(), nItems, nBins, ctx->binStart.as<u32>());
+            hipLaunchKernelGGL(k_items_bin_rank, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->binStart.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
+            return nItems;
+        }
         const u32 nWaves = (nReads + 63) / 64;
         const size_t nCells = (size_t)nBins * nWaves;
-        waitForMasks(ctx, reads);
         ctx->waveCounts.reserve((nCells + 1) * 4); ctx->waveOffsets.reserve((nCells + 1) * 4);
-        ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
         HIP_CHECK(hipMemsetAsync(ctx->waveCounts.as<u32>() + nCells, 0, 4, st));
         hipLaunchKernelGGL(k_items_count, dim3((nWaves * 64 + 255) / 256), dim3(256), 0, st, reads->masks.as<u64>(), nReads, W, nBins, ctx->waveCounts.as<u32>());
         {
@@ -396,9 +429,9 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
             ctx->scanTmp.reserve(tmpBytes + 64);
             HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nCells + 1), st));
         }
-        hipLaunchKernelGGL(k_items_bin_starts, dim3((nBins + 1 + 63) / 64), dim3(64), 0, st, ctx->waveOffsets.as<u32>(), ctx->waveOffsets.as<u32>() + nCells,
-                           nWaves, nBins, ctx->binStart.as<u32>(), ctx->binOrderRank.as<u32>());
-        u32 nItems = 0;
+        hipLaunchKernelGGL(k_items_bin_starts, dim3((nBins + 1 + 255) / 256), dim3(256), 0, st, ctx->waveOffsets.as<u32>(), ctx->waveOffsets.as<u32>() + nCells,
+                           nWaves, nBins, ctx->binStart.as<u32>());
+        hipLaunchKernelGGL(k_items_bin_rank, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->binStart.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
         HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         collectSweepTime(ctx, reads);
@@ -780,7 +813,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
             {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255},
-            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536},
+            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1},
         };
         for (auto & k : keys)
             if (!strcmp(k.name, key))

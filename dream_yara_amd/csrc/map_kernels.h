@@ -150,25 +150,78 @@ __global__ void k_items_count(const u64 * __restrict__ masks, u32 nReads, u32 W,
     }
 }
 
-// single thread: bin starts (from the exclusive scan of the bin-major count matrix) and the bin processing order of
-// sortedBins() — descending load, ties by bin number (reference src/d_mapper.h:843-854; std::sort leaves ties
-// unspecified) — as a rank per bin.
-__global__ void k_items_bin_starts(const u32 * __restrict__ waveOffsets, const u32 * __restrict__ total, u32 nWaves, u32 nBins,
-                                   u32 * __restrict__ binStart, u32 * __restrict__ binOrderRank)
+// bin starts from the exclusive scan of the bin-major count matrix
+__global__ void k_items_bin_starts(const u32 * __restrict__ waveOffsets, const u32 * __restrict__ total, u32 nWaves, u32 nBins, u32 * __restrict__ binStart)
 {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nBins) return;
     binStart[b] = b < nBins ? waveOffsets[(size_t)b * nWaves] : *total;
-    if (b == nBins) return;
-    auto load = [&](u32 x) { return (x + 1 < nBins ? waveOffsets[(size_t)(x + 1) * nWaves] : *total) - waveOffsets[(size_t)x * nWaves]; };
-    const u32 mine = load(b);
+}
+
+// The bin processing order of sortedBins() — descending load, ties by bin number (reference src/d_mapper.h:843-854; std::sort leaves
+// ties unspecified) — as a rank per bin: the loads go through LDS a tile at a time, every thread counts the bins ahead of its own.
+__global__ __launch_bounds__(256) void k_items_bin_rank(const u32 * __restrict__ binStart, u32 nBins, u32 * __restrict__ binOrderRank)
+{
+    __shared__ u32 tile[256];
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 mine = b < nBins ? binStart[b + 1] - binStart[b] : 0;
     u32 r = 0;
-    for (u32 o = 0; o < nBins; ++o)
+    for (u32 base = 0; base < nBins; base += 256)
     {
-        const u32 t = load(o);
-        if (t > mine || (t == mine && o < b)) ++r;
+        const u32 o = base + threadIdx.x;
+        tile[threadIdx.x] = o < nBins ? binStart[o + 1] - binStart[o] : 0;
+        __syncthreads();
+        const u32 cnt = min(256u, nBins - base);
+        for (u32 k = 0; k < cnt; ++k)
+        {
+            const u32 t = tile[k];
+            r += (t > mine || (t == mine && base + k < b)) ? 1u : 0u;
+        }
+        __syncthreads();
     }
-    binOrderRank[b] = r;
+    if (b < nBins) binOrderRank[b] = r;
+}
+
+// ---- the same work list without the matrix (the default): the masks are sparse (about one bin per read), so instead of a bin-major count
+// matrix of nBins x nReads/64 cells the set bits are emitted as (bin, read) pairs in read order — one thread per mask WORD, coalesced — and
+// a stable radix sort by bin gives the bin-major, read-ascending order; the bin starts are lower bounds in the sorted keys.  Per 1 M reads:
+// 1 024 bins 1.05 -> 0.33 ms, 256 bins 0.245 -> 0.137 ms, 64 bins 0.124 -> 0.114 ms.
+__global__ void k_items_word_count(const u64 * __restrict__ masks, u64 nWords, u32 W, u32 * __restrict__ readCount)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nWords) return;
+    const u64 m = masks[t];
+    if (m) atomicAdd(&readCount[t / W], (u32)__popcll(m));
+}
+
+__global__ void k_items_emit(const u64 * __restrict__ masks, u64 nWords, u32 W, u32 nBins, const u32 * __restrict__ readOffset,
+                             u16 * __restrict__ keys, u32 * __restrict__ vals)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nWords) return;
+    u64 m = masks[t];
+    if (!m) return;
+    const u32 read = (u32)(t / W), w = (u32)(t % W);
+    u32 dst = readOffset[read];
+    for (u32 k = 0; k < w; ++k) dst += (u32)__popcll(masks[t - w + k]);       // the read's earlier words: the same one or two cache lines
+    while (m)
+    {
+        const u32 j = (u32)__ffsll((long long)m) - 1;
+        m &= m - 1;
+        const u32 bin = w * 64 + j;
+        if (bin >= nBins) break;
+        keys[dst] = (u16)bin; vals[dst] = read; ++dst;
+    }
+}
+
+// binStart[b] = first item of bin b in the sorted keys (nItems for b = nBins)
+__global__ void k_items_bin_bounds(const u16 * __restrict__ keys, u32 nItems, u32 nBins, u32 * __restrict__ binStart)
+{
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nBins) return;
+    u32 lo = 0, hi = nItems;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (keys[mid] < b) lo = mid + 1; else hi = mid; }
+    binStart[b] = lo;
 }
 
 __global__ void k_items_scatter(const u64 * __restrict__ masks, u32 nReads, u32 W, u32 nBins, const u32 * __restrict__ waveOffsets,

@@ -321,7 +321,7 @@ def test_map_matches_oracle_on_gold_data(dy, ctx, ob, small_filter, strata):
 
 
 @pytest.mark.parametrize("tuning", [{"sparse_sa": 1}, {"prefix_q": 0}, {"no_isa": 1}, {"prefix_q": 6}, {"finalize_block_min": 3, "finalize_no_keys": 1},
-                                    {"ibf_full_tail": 1}])
+                                    {"ibf_full_tail": 1}, {"items_sorted": 0}])
 def test_map_without_the_device_only_tables(dy, ob, small_filter, tuning):
     """The HBM-sized tables (expanded SA, q-mer ranges, inverse SA + indexed text) only accelerate: with each of them switched
     off at load time (dy_ctx_set_tuning) the results stay identical to the oracle (sparse-SA walk, plain LF search, row-range
@@ -582,9 +582,12 @@ def test_long_reads_match_oracle(dy, ctx, ob, tmp_path):
     oidx.close(); oibf.close()
 
 
-@pytest.mark.parametrize("paired", [False, True])
-def test_more_than_64_bins_end_to_end(dy, ctx, ob, tmp_path, paired):
-    """130 bins (W = 3 mask words per read): work list, ordering, finalize and the paired-end stages with multi-word bin masks."""
+@pytest.mark.parametrize("paired,items_sorted", [(False, 1), (True, 1), (False, 0), (True, 0)])
+def test_more_than_64_bins_end_to_end(dy, ob, tmp_path, paired, items_sorted):
+    """130 bins (W = 3 mask words per read): work list, ordering, finalize and the paired-end stages with multi-word bin masks; the work
+    list built both ways (tuning key items_sorted: (bin, read) pairs + stable radix sort — the default — or the bin-major count matrix)."""
+    ctx = dy.Context(0)
+    ctx.set_tuning("items_sorted", items_sorted)
     rng = np.random.default_rng(130 + paired)
     n_bins = 130
     genomes = [rng.integers(0, 4, 6000, dtype=np.uint8) for _ in range(n_bins)]
@@ -611,7 +614,7 @@ def test_more_than_64_bins_end_to_end(dy, ctx, ob, tmp_path, paired):
     ibf.query(rd, dy.threshold(er, 14, 100), want_masks=False)
     res = dy.map_reads(ctx, idx, rd, dy.default_params(error_rate=er, strata_rate=sr, paired=1 if paired else 0))
     dev = (res.reads(), res.matches(), res.cigars()); stats = ctx.stats()
-    res.close(); rd.close(); idx.close(); ibf.close()
+    res.close(); rd.close(); idx.close(); ibf.close(); ctx.close()
     oidx = ob.OracleIndex(idx_dir, n_bins); oibf = ob.OracleIbf(fpath)
     o = ob.map_batch(oidx, oibf, codes, offs, er, sr, paired=paired)
     assert stats["items"] == o[3]["items"] and stats["raw_matches"] == o[3]["raw_matches"]
