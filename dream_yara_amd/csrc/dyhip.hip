@@ -106,8 +106,8 @@ int deviceCount()
 // ctx->counters (u32 slots, zeroed before K3): 0 unused, 1 pool overflow flag, 2 items of the wavefront-per-item list, 3 complex reads,
 // 4 align list, 5 small list, 6 DP list / rescue jobs, 7 bad raw record (dy_finalize_raw), 8 PE child list, 9 PE align list, 10 PE small list,
 // 11 PE heavy pairs, 12 busy-but-not-re-seeded items (= slot 2 + 10, see extendEasyItem), 13 inconsistent record met by k_group_matches,
-// 14-15 the 64-bit raw-match count
-enum { COUNTER_BYTES = 64, COUNTER_BAD_GROUP = 13, COUNTER_POOL64 = 14 };
+// 14-15 the 64-bit raw-match count, 16 small list / 17 DP list of the wide bands (a match with more than 3 errors)
+enum { COUNTER_BYTES = 128, COUNTER_BAD_GROUP = 13, COUNTER_POOL64 = 14, COUNTER_SMALL_WIDE = 16, COUNTER_DP_WIDE = 17 };
 
 // Explicit knobs (dy_ctx_set_tuning): which of several result-identical code paths / table sets a context uses.  The defaults are
 // the measured best; the parity tests force the other paths through this, nothing on the mapping path reads the environment.
@@ -583,30 +583,37 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         {
             ctx->alignList.reserve((size_t)nReads * 4 + 64);
             u32 * alignCount = ctx->counters.as<u32>() + 4;
-            ctx->smallList.reserve((size_t)nReads * 4 + 64);
-            u32 * smallCount = ctx->counters.as<u32>() + 5;
+            // Matches with up to 3 errors (bands of up to 7 diagonals) are aligned by the one-thread DP with 32-bit trace rows, the rare wider
+            // ones by 16 lanes each (alignMatchGroup): the lists are split by it when the batch's error budget exceeds 3.
+            const bool splitWide = maxMatchErr > 3;
+            ctx->smallList.reserve((size_t)nReads * 8 + 64);
+            u32 * smallCount = ctx->counters.as<u32>() + 5, * smallWideCount = ctx->counters.as<u32>() + COUNTER_SMALL_WIDE;
+            u32 * smallWideList = ctx->smallList.as<u32>() + nReads;
             hipLaunchKernelGGL(k_finalize_simple, dim3((nReads + 1023) / 1024), dim3(1024), 0, st, fa, ctx->complexList.as<u32>(), complexCount,
-                               ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount);
-            ctx->dpList.reserve((size_t)nReads * 4 + 64);
-            u32 * dpCount = ctx->counters.as<u32>() + 6;
-            // the three list kernels touch disjoint reads: fork after the routing kernel, join before the stage ends
+                               ctx->alignList.as<u32>(), alignCount, ctx->smallList.as<u32>(), smallCount, smallWideList, smallWideCount, splitWide ? 1u : 0u);
+            ctx->dpList.reserve((size_t)nReads * 8 + 64);
+            u32 * dpCount = ctx->counters.as<u32>() + 6, * dpWideCount = ctx->counters.as<u32>() + COUNTER_DP_WIDE;
+            u32 * dpWideList = ctx->dpList.as<u32>() + nReads;
+            // the list kernels touch disjoint reads: fork after the routing kernel, join before the stage ends
             HIP_CHECK(hipEventRecord(ctx->evFork, st));
             HIP_CHECK(hipStreamWaitEvent(ctx->side[0], ctx->evFork, 0));
             HIP_CHECK(hipStreamWaitEvent(ctx->side[1], ctx->evFork, 0));
-            // thread-level DP kernels: 64-thread blocks, trace rows in LDS ((maxLen + 1) rows x 64 threads x 4 or 8 bytes)
-            const bool narrowBand = maxMatchErr <= 3;
-            const u32 traceRows = std::min<u32>(reads->maxLen, THREAD_DP_MAX_LEN) + 1;
-            const u32 dpThreads = (size_t)traceRows * 64 * (narrowBand ? 4 : 8) > 60 * 1024 ? 32 : 64;      // stay within 64 KB of LDS per block
-            const size_t traceLds = (size_t)traceRows * dpThreads * (narrowBand ? 4 : 8);
-            if (narrowBand) hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
-            else hipLaunchKernelGGL((k_finalize_small<7, u64>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
+            // thread-level DP kernels: 64-thread blocks, trace rows in LDS ((maxLen + 1) rows x 64 threads x 4 bytes); group kernels: 256-thread
+            // blocks = 16 groups, each with its trace / sequences region
+            const u32 dpLen = std::min<u32>(reads->maxLen, THREAD_DP_MAX_LEN);
+            const u32 traceRows = dpLen + 1;
+            const u32 dpThreads = 64;
+            const size_t traceLds = (size_t)traceRows * dpThreads * 4;
+            const u32 groupLds = groupDpLdsBytes(dpLen);
+            hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
             hipLaunchKernelGGL(k_finalize_t<BlockGroup>, dim3(hugeBlocks), dim3(1024), 0, ctx->side[0], fa, blockMin + 1, 0xFFFFFFFFu, finWaves);
             hipLaunchKernelGGL(k_finalize_t<WaveGroup>, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa, 0u, blockMin, 0u);
+            if (splitWide) hipLaunchKernelGGL(k_finalize_small_group, dim3(1024), dim3(256), 16 * groupLds, ctx->side[1], fa, smallWideList, smallWideCount, groupLds);
             HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
             HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
-            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount);
-            if (narrowBand) hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
-            else hipLaunchKernelGGL((k_align_single<7, u64>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
+            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount, dpWideList, dpWideCount);
+            if (splitWide) hipLaunchKernelGGL(k_align_group, dim3(1024), dim3(256), 16 * groupLds, st, fa, dpWideList, dpWideCount, groupLds);
+            hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
             HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
         }

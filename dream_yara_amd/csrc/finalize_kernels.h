@@ -523,6 +523,140 @@ __host__ __device__ inline size_t dpScratchBytes(u32 maxReadLen, u32 maxErrors)
     return (((size_t)(maxReadLen + 1) * B + 3) & ~(size_t)3) + 6 * B * sizeof(int) + 4 * (size_t)maxReadLen + 4 * maxErrors + 32;
 }
 
+// Sub-wavefront form of alignMatchWave for the WIDE bands of short reads (more than 3 errors: 9..15 diagonals): the 16 lanes of a DPP row
+// work on one match, lane d on diagonal d of the band (B = 2e+1 <= 15), four matches per wavefront.  The one-thread form
+// (alignMatchThread<7>) needs 150 rows x 15 cells x ~30 dependent instructions per match — 1.2 ms for ONE wavefront however short the list
+// — while these bands are rare (a percent of the reads), so the 5 x higher instruction count per match of the group form does not matter
+// and its latency (a row = one cell per lane + a 4-step max-plus scan) does: 0.1 ms.  Strand-resolved read, contig infix and the trace
+// (one byte per cell) live in the group's LDS region.  Values, tie-breaks and traceback are those of alignMatchDevice.  The lanes of a
+// group must call it together with the same arguments; groups are independent (no wave-wide operation).
+__host__ __device__ inline u32 groupDpLdsBytes(u32 maxReadLen) { return ((maxReadLen + 1) * 15 + 2 * maxReadLen + 16 + 3) & ~3u; }
+// DPP row shifts (a row = 16 consecutive lanes): lane i takes the value of lane i + 1 / i - N of its row; a lane whose source lies outside
+// the row keeps its own value
+__device__ __forceinline__ int dppRowShl1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x101, 0xF, 0xF, false); }
+template <int N> __device__ __forceinline__ int dppRowShr(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x110 + N, 0xF, 0xF, false); }
+
+__device__ inline u32 alignMatchGroup(const u8 * __restrict__ ctg, int n, const u8 * __restrict__ seq, u32 readLen, u32 strand, int e,
+                                      u8 * lds, u32 * cigarOut, u32 cigarCap, int & clipBegin, int & clipEnd, u32 dLane)
+{
+    const int m = (int)readLen, B = 2 * e + 1, d = (int)dLane;
+    const int NEG = -(1 << 28), MISMATCH = -1000, GEXT = -999, GOPEN = -1001;
+    u8 * trace = lds;                                   // (m + 1) * B
+    u8 * sRead = trace + (size_t)(m + 1) * B;           // m
+    u8 * sCtg = sRead + m;                              // n <= m + e
+    for (int x = d; x < m; x += 16) sRead[x] = (u8)readBase(seq, readLen, strand, (u32)x);
+    for (int x = d; x < n; x += 16) sCtg[x] = ctg[x];
+    const bool inBand = d < B;
+    int pS, pV = NEG;
+    { const int j = d - e; pS = (inBand && j >= 0 && j <= n) ? 0 : NEG; if (inBand) trace[d] = 0; }
+    waveFence();
+    // the read base and the contig base of the NEXT row are fetched from LDS while this row computes
+    u32 rcNext = m > 0 ? sRead[0] : 0u;
+    u32 ccNext = 5u;
+    { const int j1 = 1 + d - e; if (inBand && j1 >= 1 && j1 <= n) ccNext = sCtg[j1 - 1]; }
+    for (int i = 1; i <= m; ++i)
+    {
+        const u32 rc = rcNext, cc = ccNext;
+        const int j = i + d - e;
+        const bool valid = inBand && j >= 0 && j <= n;
+        if (i < m) rcNext = sRead[i];
+        ccNext = (inBand && j >= 0 && j < n) ? sCtg[j] : 5u;              // row i+1 looks at contig base (j+1)-1
+        // vertical: from (i-1, j) = lane d+1 of the previous row
+        const int upS = dppRowShl1(pS), upV = dppRowShl1(pV);
+        int v = NEG; u32 tr = 0;
+        if (valid && d + 1 < B)
+        {
+            const int ext = upV + GEXT, opn = upS + GOPEN;
+            if (ext >= opn) { v = ext; tr |= 4; } else v = opn;
+        }
+        int t = NEG; u32 tb = 0;
+        if (valid && j >= 1) { t = pS + ((cc == rc && cc < 4) ? 0 : MISMATCH); tb = 1; }
+        if (v > t) { t = v; tb = 3; }
+        // horizontal: exclusive prefix max of U = T + 999*d over the lower diagonals of this row
+        const int u = valid ? t - GEXT * d : NEG;
+        int scan = dppRowShr<1>(u); if (d == 0) scan = NEG;
+        { const int other = dppRowShr<1>(scan); if (d >= 1 && other > scan) scan = other; }
+        { const int other = dppRowShr<2>(scan); if (d >= 2 && other > scan) scan = other; }
+        { const int other = dppRowShr<4>(scan); if (d >= 4 && other > scan) scan = other; }
+        { const int other = dppRowShr<8>(scan); if (d >= 8 && other > scan) scan = other; }
+        int h = NEG;
+        if (valid && d >= 1 && j >= 1) h = scan + GOPEN + GEXT * (d - 1);
+        int sCell = t;
+        if (h > sCell) { sCell = h; tb = 2; }
+        if (!valid) { sCell = NEG; h = NEG; v = NEG; tb = 0; tr = 0; }
+        // extend-vs-open flag of the horizontal move needs the finished left neighbour
+        const int leftS = dppRowShr<1>(sCell), leftH = dppRowShr<1>(h);
+        if (valid && d >= 1 && j >= 1 && leftH + GEXT >= leftS + GOPEN) tr |= 8;
+        if (inBand) trace[(size_t)i * B + d] = (u8)(tr | tb);
+        pS = sCell; pV = v;
+    }
+    // best cell of the last row, leftmost on ties
+    const bool lastValid = inBand && m + d - e >= 0 && m + d - e <= n;
+    const int myBest = lastValid ? pS : NEG;
+    int mx = myBest;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { const int other = __shfl_xor(mx, o, 16); mx = other > mx ? other : mx; }
+    int bd = (lastValid && myBest == mx) ? d : 16;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) { const int other = __shfl_xor(bd, o, 16); bd = other < bd ? other : bd; }
+    const int bj = m + bd - e;
+    waveFence();
+    // traceback (every lane of the group walks it: the trace reads are LDS broadcasts); cigar runs come out back to front, so they are
+    // counted first and filled from the end.  A diagonal outside the band ends the walk (it cannot happen with a trace written above;
+    // the check keeps a damaged one from steering the LDS address anywhere).
+    u32 runs = 0;
+    {
+        int ti = m, tj = bj, ts = 0, lastOp = -1;
+        while (ti > 0 && (u32)(tj - ti + e) < (u32)B)
+        {
+            const u32 tr = trace[(size_t)ti * B + (tj - ti + e)];
+            int op;
+            if (ts == 0)
+            {
+                const u32 tb = tr & 3;
+                if (tb == 1) { op = 0; --ti; --tj; }
+                else if (tb == 3) { ts = 1; continue; }
+                else if (tb == 2) { ts = 2; continue; }
+                else break;
+            }
+            else if (ts == 1) { op = 1; --ti; if (!(tr & 4)) ts = 0; }
+            else { op = 2; --tj; if (!(tr & 8)) ts = 0; }
+            if (op != lastOp) { ++runs; lastOp = op; }
+        }
+        clipBegin = tj;
+    }
+    clipEnd = bj;
+    if (cigarOut && d == 0)
+    {
+        int i = m, j = bj, state = 0, lastOp = -1;
+        u32 slot = runs, run = 0;
+        while (i > 0 && (u32)(j - i + e) < (u32)B)
+        {
+            const u32 tr = trace[(size_t)i * B + (j - i + e)];
+            int op;
+            if (state == 0)
+            {
+                const u32 tb = tr & 3;
+                if (tb == 1) { op = 0; --i; --j; }
+                else if (tb == 3) { state = 1; continue; }
+                else if (tb == 2) { state = 2; continue; }
+                else break;
+            }
+            else if (state == 1) { op = 1; --i; if (!(tr & 4)) state = 0; }
+            else { op = 2; --j; if (!(tr & 8)) state = 0; }
+            if (op != lastOp)
+            {
+                if (lastOp >= 0) { --slot; if (slot < cigarCap) cigarOut[slot] = (run << 4) | (u32)lastOp; }
+                lastOp = op; run = 0;
+            }
+            ++run;
+        }
+        if (lastOp >= 0) { --slot; if (slot < cigarCap) cigarOut[slot] = (run << 4) | (u32)lastOp; }
+    }
+    waveFence();            // the region is reused by the group's next match
+    return runs;
+}
+
 // ---- who works on one read in k_finalize_t: a wavefront (almost every read) or a whole 1024-thread block (reads with thousands of
 // matches: repeats, low-complexity runs — one wavefront would sort them alone for seconds).  Same code, different primitives.
 struct WaveGroup
@@ -1024,11 +1158,13 @@ __device__ __forceinline__ void blockAppend(const bool (&want)[NL], u32 value, u
     __syncthreads();
 }
 
+// splitWide (the batch may hold matches with more than 3 errors): small-list reads with such a match go to smallWideList (k_finalize_small_group)
 __global__ __launch_bounds__(1024) void k_finalize_simple(FinalizeArgs A, u32 * __restrict__ complexList, u32 * __restrict__ complexCount,
-                                  u32 * __restrict__ alignList, u32 * __restrict__ alignCount, u32 * __restrict__ smallList, u32 * __restrict__ smallCount)
+                                  u32 * __restrict__ alignList, u32 * __restrict__ alignCount, u32 * __restrict__ smallList, u32 * __restrict__ smallCount,
+                                  u32 * __restrict__ smallWideList, u32 * __restrict__ smallWideCount, u32 splitWide)
 {
     const u32 read = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 route = 0;      // 0 = done here, 1 = align list, 2 = small list, 3 = complex list
+    u32 route = 0;      // 0 = done here, 1 = align list, 2 = small list, 3 = complex list, 4 = small list, wide band
     if (read < A.nReads)
     {
         const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
@@ -1053,31 +1189,35 @@ __global__ __launch_bounds__(1024) void k_finalize_simple(FinalizeArgs A, u32 * 
                     route = 1;      // alignment needed, but nothing to sort: k_align_check / k_align_single (all lanes busy there)
             }
             else if (n <= 4 && readLen <= THREAD_DP_MAX_LEN && readErrorsOf(readLen, A.errorRate) <= THREAD_DP_MAX_E)
+            {
                 route = 2;
+                if (splitWide)
+                    for (u32 i = 0; i < n; ++i) if (A.gp[s0 + i].errors > 3) route = 4;
+            }
         }
     }
-    const bool want[3] = {route == 1, route == 2, route == 3};
-    u32 * const lists[3] = {alignList, smallList, complexList};
-    u32 * const counts[3] = {alignCount, smallCount, complexCount};
-    blockAppend<3>(want, read, lists, counts);
+    const bool want[4] = {route == 1, route == 2, route == 3, route == 4};
+    u32 * const lists[4] = {alignList, smallList, complexList, smallWideList};
+    u32 * const counts[4] = {alignCount, smallCount, complexCount, smallWideCount};
+    blockAppend<4>(want, read, lists, counts);
 }
 
 // First pass over the align list: a 2-substitution match needs no DP when alignIsUngapped2 holds; the rest goes to dpList.
 __global__ __launch_bounds__(256) void k_align_check(FinalizeArgs A, const u32 * __restrict__ alignList, const u32 * __restrict__ alignCount,
-                                                     u32 * __restrict__ dpList, u32 * __restrict__ dpCount)
+                                                     u32 * __restrict__ dpList, u32 * __restrict__ dpCount, u32 * __restrict__ dpWideList, u32 * __restrict__ dpWideCount)
 {
     const u32 nList = *alignCount;
     for (u32 base = blockIdx.x * blockDim.x; base < nList; base += gridDim.x * blockDim.x)
     {
         const u32 li = base + threadIdx.x;
-        bool needDp = false; u32 read = 0;
+        bool needDp = false, wide = false; u32 read = 0;
         if (li < nList)
         {
             read = alignList[li];
             const u32 s0 = A.readStart[read];
             const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
             const RawMatch a = A.gp[s0];
-            needDp = true;
+            needDp = true; wide = a.errors > 3;
             if (a.errors == 2 && a.len == readLen && readLen >= 8)
             {
                 const BinDesc & bd = A.bins[a.bin];
@@ -1092,10 +1232,11 @@ __global__ __launch_bounds__(256) void k_align_check(FinalizeArgs A, const u32 *
                 }
             }
         }
-        const bool want[1] = {needDp};
-        u32 * const lists[1] = {dpList};
-        u32 * const counts[1] = {dpCount};
-        blockAppend<1>(want, read, lists, counts);
+        // up to 3 errors (7 diagonals): k_align_single<3>; more: k_align_group
+        const bool want[2] = {needDp && !wide, needDp && wide};
+        u32 * const lists[2] = {dpList, dpWideList};
+        u32 * const counts[2] = {dpCount, dpWideCount};
+        blockAppend<2>(want, read, lists, counts);
     }
 }
 
@@ -1144,8 +1285,10 @@ __device__ __forceinline__ void insertionSortIdx(u32 * idx, u32 cnt, TLess less)
 // co-optimal entry (single-end: the child's own random pick), {false, i} = the i-th unique entry in coordinate order (paired-end:
 // the pairing stage has chosen).
 struct SmallPrimary { bool amongOptimal; u32 index; };
-template <int EMAX, typename TRow, typename TPrimaryOf>
-__device__ inline void finalizeSmallRead(const FinalizeArgs & A, u32 read, ReadOut & ro, TRow * trace, u32 traceStride, TPrimaryOf primaryOf)
+// alignFn(ctg, n, seq, readLen, strand, e, cigarOut, cigarCap, cb, ce) is the alignment DP; `writer` = this thread stores the results
+// (the 16 lanes of a group run the aggregation redundantly around alignMatchGroup; one of them writes).
+template <typename TAlign, typename TPrimaryOf>
+__device__ inline void finalizeSmallRead(const FinalizeArgs & A, u32 read, ReadOut & ro, TAlign alignFn, bool writer, TPrimaryOf primaryOf)
 {
     const u32 s0 = A.readStart[read], n = A.readStart[read + 1] - s0;
     const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
@@ -1199,12 +1342,11 @@ __device__ inline void finalizeSmallRead(const FinalizeArgs & A, u32 read, ReadO
                     const BinDesc & bd = A.bins[a.bin];
                     const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
                     int cb, ce;
-                    const u32 nc = alignMatchThread<EMAX, TRow>(ctg, (int)a.len, seq, readLen, a.strand, (int)a.errors,
-                                                                winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce, trace, traceStride);
+                    const u32 nc = alignFn(ctg, (int)a.len, seq, readLen, (u32)a.strand, (int)a.errors, winner ? A.cigars + ro.cigarBegin : nullptr, A.cigarStride, cb, ce);
                     if (winner) ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
                     a.begin += (u32)cb; a.len = (u16)ce;
                 }
-                else if (winner) { A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
+                else if (winner) { if (writer) A.cigars[ro.cigarBegin] = (readLen << 4) | 0; ro.cigarLen = 1; }
                 if (winner) { winErr = primErr; winRank = binRank; }
             }
             M[nM++] = a;
@@ -1230,7 +1372,7 @@ __device__ inline void finalizeSmallRead(const FinalizeArgs & A, u32 read, ReadO
     {
         const RawMatch a = M[idxM[q]];
         OutMatch om; om.contig = A.bins[a.bin].contigIdBase + a.contig; om.begin = a.begin; om.length = a.len; om.errors = a.errors; om.isRev = a.strand;
-        A.outSet[(size_t)ro.setBegin + q] = om;
+        if (writer) A.outSet[(size_t)ro.setBegin + q] = om;
         if (q == pick)
         {
             ro.contig = om.contig; ro.begin = om.begin; ro.length = om.length; ro.errors = om.errors; ro.isRev = om.isRev;
@@ -1238,8 +1380,24 @@ __device__ inline void finalizeSmallRead(const FinalizeArgs & A, u32 read, ReadO
         }
     }
     ro.bestCount = nOpt; ro.subCount = nSet - nOpt;
-    A.out[read] = ro;
+    if (writer) A.out[read] = ro;
 }
+
+// the one-thread DP as finalizeSmallRead's alignFn
+template <int EMAX, typename TRow>
+struct ThreadAligner
+{
+    TRow * trace; u32 traceStride;
+    __device__ __forceinline__ u32 operator()(const u8 * ctg, int n, const u8 * seq, u32 readLen, u32 strand, int e, u32 * cigarOut, u32 cigarCap, int & cb, int & ce) const
+    { return alignMatchThread<EMAX, TRow>(ctg, n, seq, readLen, strand, e, cigarOut, cigarCap, cb, ce, trace, traceStride); }
+};
+// 16 lanes per match
+struct GroupAligner
+{
+    u8 * lds; u32 d;
+    __device__ __forceinline__ u32 operator()(const u8 * ctg, int n, const u8 * seq, u32 readLen, u32 strand, int e, u32 * cigarOut, u32 cigarCap, int & cb, int & ce) const
+    { return alignMatchGroup(ctg, n, seq, readLen, strand, e, lds, cigarOut, cigarCap, cb, ce, d); }
+};
 
 template <int EMAX, typename TRow>
 __global__ __launch_bounds__(64) void k_finalize_small(FinalizeArgs A, const u32 * __restrict__ smallList, const u32 * __restrict__ smallCount)
@@ -1251,7 +1409,51 @@ __global__ __launch_bounds__(64) void k_finalize_small(FinalizeArgs A, const u32
     {
         const u32 read = smallList[li];
         ReadOut ro; initReadOut(ro, 3 * A.readStart[read], read * A.cigarStride);
-        finalizeSmallRead<EMAX, TRow>(A, read, ro, trace, blockDim.x, [](u32, u32 nOptB) { return SmallPrimary{true, libcxxFirstUniform(nOptB)}; });
+        finalizeSmallRead(A, read, ro, ThreadAligner<EMAX, TRow>{trace, blockDim.x}, true, [](u32, u32 nOptB) { return SmallPrimary{true, libcxxFirstUniform(nOptB)}; });
+    }
+}
+
+// The reads of the small list that hold a match with more than 3 errors, 16 lanes per read (alignMatchGroup): `ldsPerGroup` bytes of
+// dynamic LDS per group of the block
+__global__ __launch_bounds__(256) void k_finalize_small_group(FinalizeArgs A, const u32 * __restrict__ smallList, const u32 * __restrict__ smallCount, u32 ldsPerGroup)
+{
+    extern __shared__ u64 dpTraceLds[];
+    const u32 d = threadIdx.x & 15, groupInBlock = threadIdx.x >> 4, groupsPerBlock = blockDim.x >> 4;
+    u8 * lds = (u8 *)dpTraceLds + (size_t)groupInBlock * ldsPerGroup;
+    const u32 nList = min(*smallCount, A.nReads);          // a list never holds more than every read once
+    for (u32 li = blockIdx.x * groupsPerBlock + groupInBlock; li < nList; li += gridDim.x * groupsPerBlock)
+    {
+        const u32 read = smallList[li];
+        ReadOut ro; initReadOut(ro, 3 * A.readStart[read], read * A.cigarStride);
+        finalizeSmallRead(A, read, ro, GroupAligner{lds, d}, d == 0, [](u32, u32 nOptB) { return SmallPrimary{true, libcxxFirstUniform(nOptB)}; });
+    }
+}
+
+// k_align_single for the matches with more than 3 errors, 16 lanes per match
+__global__ __launch_bounds__(256) void k_align_group(FinalizeArgs A, const u32 * __restrict__ alignList, const u32 * __restrict__ alignCount, u32 ldsPerGroup)
+{
+    extern __shared__ u64 dpTraceLds[];
+    const u32 d = threadIdx.x & 15, groupInBlock = threadIdx.x >> 4, groupsPerBlock = blockDim.x >> 4;
+    u8 * lds = (u8 *)dpTraceLds + (size_t)groupInBlock * ldsPerGroup;
+    const u32 nList = min(*alignCount, A.nReads);
+    for (u32 li = blockIdx.x * groupsPerBlock + groupInBlock; li < nList; li += gridDim.x * groupsPerBlock)
+    {
+        const u32 read = alignList[li];
+        const u32 s0 = A.readStart[read];
+        const u32 readLen = (u32)(A.readOffs[read + 1] - A.readOffs[read]);
+        ReadOut ro; initReadOut(ro, 3 * s0, read * A.cigarStride);
+        RawMatch a = A.gp[s0];
+        const BinDesc & bd = A.bins[a.bin];
+        const u8 * ctg = A.contigs + bd.contigOff + A.limits[bd.limOff + a.contig] + a.begin;
+        int cb, ce;
+        const u32 nc = alignMatchGroup(ctg, (int)a.len, A.readSeqs + A.readOffs[read], readLen, a.strand, (int)a.errors, lds,
+                                       A.cigars + ro.cigarBegin, A.cigarStride, cb, ce, d);
+        if (d == 0)
+        {
+            ro.cigarLen = nc < A.cigarStride ? nc : A.cigarStride;
+            a.begin += (u32)cb; a.len = (u16)ce;
+            writeSingleMatch(A, read, ro, a);
+        }
     }
 }
 

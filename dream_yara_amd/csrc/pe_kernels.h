@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64) void k_pe_finalize_small(FinalizeArgs A, PeView
         const PeItem it = V.items[peFindItem(V, read, bin)];
         ReadOut ro; initReadOut(ro, mStart[read], read * A.cigarStride);
         ro.paired = it.paired ? 1 : 0; ro.pairProb = it.paired ? it.prob : 0.0;
-        finalizeSmallRead<EMAX, TRow>(A, read, ro, trace, blockDim.x, [&](u32, u32) { return SmallPrimary{false, it.primary}; });
+        finalizeSmallRead(A, read, ro, ThreadAligner<EMAX, TRow>{trace, blockDim.x}, true, [&](u32, u32) { return SmallPrimary{false, it.primary}; });
     }
 }
 
