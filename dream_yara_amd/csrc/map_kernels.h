@@ -72,6 +72,11 @@ __device__ __forceinline__ int lcpForward(const u8 * __restrict__ a, const u8 * 
         const u64 f = mismatchFlags(load8(a + i), load8(b + i));
         if (f) return i + (__ffsll((long long)f) - 1) / 8;
     }
+    if (i < n && n >= 8)
+    {   // the last 1..7 bytes as one 8-byte chunk ending at n (its first bytes are known to be equal) instead of a round trip per byte
+        const u64 f = mismatchFlags(load8(a + n - 8), load8(b + n - 8));
+        return f ? n - 8 + (__ffsll((long long)f) - 1) / 8 : n;
+    }
     for (; i < n; ++i) { const u32 x = a[i], y = b[i]; if (!(x == y && x < 4)) break; }
     return i;
 }
@@ -94,13 +99,37 @@ __device__ __forceinline__ int lcpBackward(const u8 * __restrict__ a, const u8 *
         const u64 f = mismatchFlags(load8(a - i - 8), load8(b - i - 8));
         if (f) return i + __clzll((long long)f) / 8;
     }
+    if (i < n && n >= 8)
+    {
+        const u64 f = mismatchFlags(load8(a - n), load8(b - n));
+        return f ? n - 8 + __clzll((long long)f) / 8 : n;
+    }
     for (; i < n; ++i) { const u32 x = a[-1 - i], y = b[-1 - i]; if (!(x == y && x < 4)) break; }
     return i;
 }
+// mismatches of a[0..n) against b[0..n), 32 bytes per step with every load issued before the first count; there is no 8-byte / single-byte
+// tail: the chunks of the last step are CLAMPED to end at n (chunk k starts at min(i + 8k, n - 8)) and the bytes a clamped chunk re-reads
+// are masked out of its flags — K2's 13-byte verification is one round trip instead of two
 __device__ __forceinline__ u32 countMismatches(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
 {
     u32 c = 0; int i = 0;
-    for (; i + 8 <= n; i += 8) c += (u32)__popcll(mismatchFlags(load8(a + i), load8(b + i)));
+    if (n >= 8)
+    {
+        const int last = n - 8;
+        for (; i < n; i += 32)
+        {
+            u64 f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+                const int start = i + 8 * k, o = start < last ? start : last;
+                const u64 x = mismatchFlags(load8(a + o), load8(b + o));
+                f[k] = start < n ? x & (~0ull << (8 * (start - o))) : 0ull;
+            }
+            c += (u32)(__popcll(f[0]) + __popcll(f[1]) + __popcll(f[2]) + __popcll(f[3]));
+        }
+        return c;
+    }
     for (; i < n; ++i) { const u32 x = a[i], y = b[i]; c += !(x == y && x < 4); }
     return c;
 }

@@ -355,7 +355,19 @@ __global__ __launch_bounds__(1024) void k_pe_library(PeView V)
                     const u32 m = min(4096u, nKept - base);
                     for (u32 i = tid; i < m; i += nThreads) chunk[i] = (float)kept[base + i];
                     __syncthreads();
-                    if (tid == 0) for (u32 i = 0; i < m; ++i) { const float d = chunk[i] - mean; sq += d * d; }
+                    if (tid == 0)
+                    {   // only the additions form the chain: the squares of eight elements are formed ahead of it
+                        u32 i = 0;
+                        for (; i + 8 <= m; i += 8)
+                        {
+                            float q[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { const float d = chunk[i + k] - mean; q[k] = d * d; }
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) sq += q[k];
+                        }
+                        for (; i < m; ++i) { const float d = chunk[i] - mean; sq += d * d; }
+                    }
                     __syncthreads();
                 }
                 if (tid == 0)
