@@ -503,8 +503,10 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             {
                 // the longest seed a read of the batch can be cut into: a short read with few errors may be ONE seed (ceil((e + 1) / 3) = 1)
                 const u32 maxSeedLen = reads->maxLen;
-                if (nw <= 2) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
-                else if (nw <= 4) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
+                // the kernels for reads of up to 256 bases hold the extension's edit-distance band in one word (myers_device.h): at most 31 errors
+                const bool bandFits = readErrorsOf(reads->maxLen, p->error_rate) <= 31;
+                if (nw <= 2 && bandFits) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
+                else if (nw <= 4 && bandFits) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 HIP_CHECK(hipGetLastError());

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "dy_types.h"
 #include "fm_device.h"
+#include "myers_device.h"
 
 namespace dy {
 
@@ -386,72 +387,6 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
     hits0[(size_t)item * slots + slot] = res;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Bit-parallel prefix edit distance (Myers/Hyyro block algorithm, global start): stands in for SeqAn's
-// Myers<AlignTextBanded<FindPrefix, NMatchesNone_, NMatchesNone_>> as used by find_extender.h:159-168,233-248.
-// Reports, in increasing text end j, every prefix text[0..j) with ed(needle, prefix) <= k (j = 0 too when m <= k).
-// N (code 4) matches nothing.  NW = 64-bit words covering the needle.
-// ---------------------------------------------------------------------------------------------------
-template <int NW, typename TNeedle, typename TText, typename TReport>
-__device__ __forceinline__ void myersPrefixSearch(TNeedle needle, int m, TText text, int t, int k, TReport report)
-{
-    if (m <= k) report(-1, m);
-    if (m == 0)
-    {   // D[0][j] = j
-        for (int j = 1; j <= t && j <= k; ++j) report(j - 1, j);
-        return;
-    }
-    u64 peq[4][NW], vp[NW], vn[NW];
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { peq[0][w] = peq[1][w] = peq[2][w] = peq[3][w] = 0; vp[w] = ~0ull; vn[w] = 0; }
-    for (int i = 0; i < m; ++i)
-    {
-        u32 c = needle(i);
-        if (c < 4)
-        {
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-                if ((i >> 6) == w) { u64 bit = 1ull << (i & 63); if (c == 0) peq[0][w] |= bit; else if (c == 1) peq[1][w] |= bit; else if (c == 2) peq[2][w] |= bit; else peq[3][w] |= bit; }
-        }
-    }
-    const int lastWord = (m - 1) >> 6;
-    const u64 lastBit = 1ull << ((m - 1) & 63);
-    int score = m;
-    const int jmax = t < m + k ? t : m + k;
-    for (int j = 1; j <= jmax; ++j)
-    {
-        u32 c = text(j - 1);
-        int hin = 1;                      // global start: D[0][j] = D[0][j-1] + 1
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-        {
-            if (w <= lastWord)
-            {
-                u64 eq = c == 0 ? peq[0][w] : c == 1 ? peq[1][w] : c == 2 ? peq[2][w] : c == 3 ? peq[3][w] : 0ull;
-                const u64 pv = vp[w], mv = vn[w];
-                const u64 hinNeg = hin < 0 ? 1ull : 0ull;
-                const u64 xv = eq | mv;
-                eq |= hinNeg;
-                const u64 xh = (((eq & pv) + pv) ^ pv) | eq;
-                u64 ph = mv | ~(xh | pv);
-                u64 mh = pv & xh;
-                const u64 top = (w == lastWord) ? lastBit : (1ull << 63);
-                int hout = 0;
-                if (ph & top) hout = 1;
-                if (mh & top) hout = -1;
-                ph <<= 1; mh <<= 1;
-                mh |= hinNeg;
-                if (hin > 0) ph |= 1ull;
-                vp[w] = mh | ~(xv | ph);
-                vn[w] = ph & xv;
-                hin = hout;
-            }
-        }
-        score += hin;
-        if (score <= k) report(j - 1, score);
-    }
-}
-
 struct ItemState
 {
     u32 minErrors;     // 255 = none yet (ReadsContext::minErrors, reference src/bits_context.h:86)
@@ -515,7 +450,7 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
             auto textAt = [&](int j) -> u32 {
                 if ((j & 7) == 0) { if (hb >= (u32)j + 7) tw = load8(ctg + hb - j - 7); else { tw = 0; for (u32 t = 0; t < 8 && (u32)j + t <= hb; ++t) tw |= (u64)ctg[hb - j - t] << (8 * (7 - t)); } }
                 return (u32)(tw >> (8 * (7 - (j & 7)))) & 0xff; };
-            myersPrefixSearch<NW>(needleAt, ndlLen - lcp, textAt, hayLen - lcp, (int)remaining,
+            prefixSearch<NW>(needleAt, ndlLen - lcp, textAt, hayLen - lcp, (int)remaining,
                                   [&](int pos, int dist) { if ((u32)dist <= minErr) { minErr = (u32)dist; endPos = pos + 1; } });
             errors += minErr;
             matchBegin -= (u32)(endPos + lcp);
@@ -550,7 +485,7 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
             u64 nw = 0, tw = 0;        // forward: an 8-byte load may run past the needle / window, never past the padded arrays
             auto needleAt = [&](int i) -> u32 { if ((i & 7) == 0) nw = load8(seq + nb + i); return (u32)(nw >> (8 * (i & 7))) & 0xff; };
             auto textAt = [&](int j) -> u32 { if ((j & 7) == 0) tw = load8(ctg + hb + j); return (u32)(tw >> (8 * (j & 7))) & 0xff; };
-            myersPrefixSearch<NW>(needleAt, nl - 1, textAt, hl - 1, (int)remaining,
+            prefixSearch<NW>(needleAt, nl - 1, textAt, hl - 1, (int)remaining,
                                   [&](int pos, int dist) {
                                       const int currentEnd = pos + 1;
                                       u32 cur = (u32)dist;
@@ -832,7 +767,7 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
 }
 
 #ifndef DY_K3_WAVES
-#define DY_K3_WAVES 4      // waves per SIMD the easy-path kernel is compiled for at NW <= 2 (measured: 4 -> 1.10 ms, 5 -> 1.11 ms, 6 -> 1.20 ms: spills eat the gain)
+#define DY_K3_WAVES 5      // waves per SIMD the easy-path kernel is compiled for at NW <= 2 (with the one-word banded edit distance: 4 -> 0.660 ms, 5 -> 0.646 ms, 6 -> 0.692 ms per 1 M reads)
 #endif
 
 // Hard item: re-seeded with seedErrors = 1 or 2 (buckets 1 / 2), Hamming backtracking in the FM index.
