@@ -111,23 +111,34 @@ __device__ __forceinline__ int lcpBackward(const u8 * __restrict__ a, const u8 *
 // mismatches of a[0..n) against b[0..n), 32 bytes per step with every load issued before the first count; there is no 8-byte / single-byte
 // tail: the chunks of the last step are CLAMPED to end at n (chunk k starts at min(i + 8k, n - 8)) and the bytes a clamped chunk re-reads
 // are masked out of its flags — K2's 13-byte verification is one round trip instead of two
+// CH = chunks per step: 4 where the ranges are long (K3's 25-byte seed check is one round trip), 2 where registers decide the kernel's
+// occupancy (K2: its 7..13-byte verification fits one step anyway)
+// PADDED = both arrays are readable for 8 bytes from a / b whatever n is (the indexed text and the read arrays end in 64 spare bytes):
+// fewer than 8 bytes are then one masked chunk instead of a round trip per byte.
+template <int CH = 4, bool PADDED = false>
 __device__ __forceinline__ u32 countMismatches(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
 {
     u32 c = 0; int i = 0;
+    if (PADDED && n < 8) return n > 0 ? (u32)__popcll(mismatchFlags(load8(a), load8(b)) & (~0ull >> (8 * (8 - n)))) : 0u;
     if (n >= 8)
     {
         const int last = n - 8;
-        for (; i < n; i += 32)
+        for (; i < n; i += 8 * CH)
         {
-            u64 f[4];
+            u64 av[CH], bv[CH];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < CH; ++k)
+            {   // only the chunks that start inside [0, n) are fetched (K2 is bound by its requests)
+                const int start = i + 8 * k, o = start < last ? start : last;
+                av[k] = 0; bv[k] = 0;
+                if (start < n) { av[k] = load8(a + o); bv[k] = load8(b + o); }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
             {
                 const int start = i + 8 * k, o = start < last ? start : last;
-                const u64 x = mismatchFlags(load8(a + o), load8(b + o));
-                f[k] = start < n ? x & (~0ull << (8 * (start - o))) : 0ull;
+                if (start < n) c += (u32)__popcll(mismatchFlags(av[k], bv[k]) & (~0ull << (8 * (start - o))));
             }
-            c += (u32)(__popcll(f[0]) + __popcll(f[1]) + __popcll(f[2]) + __popcll(f[3]));
         }
         return c;
     }
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
                     if (x >= rem)                                                // else the seed would start before the contig does
                     {
                         const u8 * pat = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off + d0;
-                        if (!countMismatches(ix.ftext + ix.bins[bin].contigOff + lim + (clen - x), pat, (int)rem)) hit = make_uint2(x - rem, DIRECT_HIT | contig);
+                        if (!countMismatches<2, true>(ix.ftext + ix.bins[bin].contigOff + lim + (clen - x), pat, (int)rem)) hit = make_uint2(x - rem, DIRECT_HIT | contig);
                     }
                     hits0[(size_t)item * slots + slot] = hit;
                     return;
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
                     const u64 lim = b.limits[contig];
                     const u32 clen = (u32)(b.limits[contig + 1] - lim);
                     if (x < rem) continue;
-                    if (countMismatches(ftext + lim + (clen - x), pat, (int)rem)) continue;
+                    if (countMismatches<2, true>(ftext + lim + (clen - x), pat, (int)rem)) continue;
                     ++found;
                     oneX = x - rem; oneContig = contig;
                     if (found > 1 || row + 1 < hi) first = min(first, isa[lim + x - rem]);
