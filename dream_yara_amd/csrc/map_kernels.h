@@ -330,15 +330,13 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
         {   // first q characters through the q-mer table
             // the seed is contiguous in the strand's own array (seqsRc holds the reverse complements): 8 bases per load
             u32 idx = 0;
-            {
+            {   // q <= 12 bases = two 8-byte words, both requested at once (they may run past the read: the arrays end in 64 spare bytes)
                 const u8 * pat0 = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off;
-                for (u32 d = 0; d < ix.prefixQ; d += 8)
+                const u64 w0 = load8(pat0), w1 = load8(pat0 + 8);
+                for (u32 d = 0; d < ix.prefixQ; ++d)
                 {
-                    const u32 take = min(8u, ix.prefixQ - d);
-                    u64 wv = 0;
-                    if (off + d + 8 <= len) wv = load8(pat0 + d);
-                    else for (u32 t = 0; t < take; ++t) wv |= (u64)pat0[d + t] << (8 * t);
-                    for (u32 t = 0; t < take; ++t) { const u32 c = (u32)(wv >> (8 * t)) & 0xff; ok &= c < 4; idx = idx * 4 + (c & 3); }
+                    const u32 c = (u32)((d < 8 ? w0 >> (8 * d) : w1 >> (8 * (d - 8))) & 0xff);
+                    ok &= c < 4; idx = idx * 4 + (c & 3);
                 }
             }
             d0 = ix.prefixQ;
