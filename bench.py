@@ -325,7 +325,7 @@ def main():
                 secondary = {"kernel": "k_seed_search (K2: FM backward search / LF-mapping)", "bound": "l2", "l2_hit_rate": hit / max(1.0, hit + miss),
                              "l2_requests_per_launch": hit + miss, "fetched_bytes_per_launch": k2.get("FETCH_SIZE", 0.0) * 1024.0,
                              "ms_per_launch": leg["stage_ms_per_step"]["ms_search"] / n_batches, "source": "profiles/" + os.path.basename(pmc_file),
-                             "note": "items are bin-major and the block->item mapping gives each XCD a contiguous slice, so an XCD's 4 MiB L2 holds the rank dictionary of the bin it walks; misses are served by the Infinity Cache"}
+                             "note": "K2 resolves a seed with one gather into the q-mer range table and one compare against the indexed text (both HBM-sized: every one an L2 miss, a 128-B line slot each) and walks the rank dictionary (L2-resident per XCD: items are bin-major, an XCD gets a contiguous slice) only for repeats; what hits the L2 are the read bases and the contig limits"}
         line = {
             "metric": "mapped reads/sec (whole node), 100 bp SE, 64-bin IBF",
             "value": leg["value"], "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
