@@ -332,29 +332,23 @@ __device__ inline u32 alignMatchThread(const u8 * __restrict__ ctg, int n, const
         for (int d = 0; d < BM; ++d)
         {
             const int j = i + d - e;
-            int s = NEG, h = NEG, v = NEG; u32 tr = 0;
-            if (d < B && j >= 0 && j <= n)
-            {
-                if (d + 1 < B)
-                {
-                    const int ext = pV[d + 1 < BM ? d + 1 : d] + GEXT, opn = pS[d + 1 < BM ? d + 1 : d] + GOPEN;
-                    if (ext >= opn) { v = ext; tr |= 4; } else v = opn;
-                }
-                if (d >= 1 && j >= 1)
-                {
-                    const int ext = leftH + GEXT, opn = leftS + GOPEN;
-                    if (ext >= opn) { h = ext; tr |= 8; } else h = opn;
-                }
-                u32 tb = 0;
-                if (j >= 1)
-                {
-                    const u32 cc = cw[d];
-                    s = pS[d] + ((cc == rc && cc < 4) ? 0 : MISMATCH); tb = 1;
-                }
-                if (v > s) { s = v; tb = 3; }
-                if (h > s) { s = h; tb = 2; }
-                tr |= tb;
-            }
+            // straight-line (selects instead of a branch region per cell: a lone wavefront pays for every exec-mask switch); NEG stays
+            // far from overflow however many gap steps are added to it
+            const bool valid = d < B && j >= 0 && j <= n;
+            const bool useV = valid && d + 1 < B, useH = valid && d >= 1 && j >= 1, useD = valid && j >= 1;
+            const int vExt = pV[d + 1 < BM ? d + 1 : d] + GEXT, vOpn = pS[d + 1 < BM ? d + 1 : d] + GOPEN;
+            const bool vE = vExt >= vOpn;
+            const int v = useV ? (vE ? vExt : vOpn) : NEG;
+            const int hExt = leftH + GEXT, hOpn = leftS + GOPEN;
+            const bool hE = hExt >= hOpn;
+            const int h = useH ? (hE ? hExt : hOpn) : NEG;
+            const u32 cc = cw[d];
+            int s = useD ? pS[d] + ((cc == rc && cc < 4) ? 0 : MISMATCH) : NEG;
+            u32 tb = useD ? 1u : 0u;
+            if (v > s) { s = v; tb = 3; }
+            if (h > s) { s = h; tb = 2; }
+            if (!valid) { s = NEG; tb = 0; }
+            const u32 tr = tb | ((useV && vE) ? 4u : 0u) | ((useH && hE) ? 8u : 0u);
             cS[d] = s; cV[d] = v; leftS = s; leftH = h;
             row |= (TRow)tr << (4 * d);
         }
