@@ -115,6 +115,14 @@ __device__ __forceinline__ void waveFence()
     __builtin_amdgcn_wave_barrier();
 }
 
+// the same for data exchanged through LDS only: the wavefront's LDS operations have completed (its global stores may still be in flight —
+// a full fence per DP row made the row loop wait ~2 us for the trace bytes it had just stored)
+__device__ __forceinline__ void waveFenceLds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ u32 waveMin32(u32 v) { for (int o = 32; o >= 1; o >>= 1) { u32 t = __shfl_xor(v, o, 64); v = t < v ? t : v; } return v; }
 __device__ __forceinline__ u32 waveSum32(u32 v) { for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
 
@@ -528,6 +536,20 @@ __host__ __device__ inline u32 groupDpLdsBytes(u32 maxReadLen) { return ((maxRea
 // DPP row shifts (a row = 16 consecutive lanes): lane i takes the value of lane i + 1 / i - N of its row; a lane whose source lies outside
 // the row keeps its own value
 __device__ __forceinline__ int dppRowShl1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x101, 0xF, 0xF, false); }
+// whole-wavefront forms (gfx9 DPP): lane i takes lane i - 1, lane 0 takes `first`; inclusive running maximum over the 64 lanes (shifts inside
+// the 16-lane rows, then the last lane of a row broadcast into the rows behind it) — a dozen cycles each where a ds_bpermute shuffle takes ~100
+__device__ __forceinline__ int dppWaveShr1(int x, int first) { return __builtin_amdgcn_update_dpp(first, x, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int dppWaveMaxScan(int x)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(x, x, 0x111, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:1
+    t = __builtin_amdgcn_update_dpp(x, x, 0x112, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:2
+    t = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:4
+    t = __builtin_amdgcn_update_dpp(x, x, 0x118, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:8
+    t = __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false); x = t > x ? t : x;      // row_bcast:15 into rows 1 and 3
+    t = __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false); x = t > x ? t : x;      // row_bcast:31 into rows 2 and 3
+    return x;
+}
 template <int N> __device__ __forceinline__ int dppRowShr(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x110 + N, 0xF, 0xF, false); }
 
 __device__ inline u32 alignMatchGroup(const u8 * __restrict__ ctg, int n, const u8 * __restrict__ seq, u32 readLen, u32 strand, int e,

@@ -636,27 +636,25 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
                 if (v > tt) { tt = v; tb = 3; }
                 // horizontal matrix: H[j] = max_{j'<j} (T[j'] + open + ext*(j-j'-1)); exclusive prefix max of U = T + 999 j
                 const int u = valid ? tt - GEXT * j : NEG;
-                int incl = u;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const int other = __shfl_up(incl, o, 64); if ((int)lane >= o && other > incl) incl = other; }
-                int excl = __shfl_up(incl, 1, 64); if (lane == 0) excl = NEG;
+                const int incl = dppWaveMaxScan(u);
+                const int excl = dppWaveShr1(incl, NEG);
                 const int scan = excl > carryScan ? excl : carryScan;
                 int h = NEG;
                 if (valid && j >= 1) h = scan + GOPEN + GEXT * (j - 1);
                 int sCell = tt;
                 if (h > sCell) { sCell = h; tb = 2; }
                 if (!valid) { sCell = NEG; h = NEG; v = NEG; }
-                int leftS = __shfl_up(sCell, 1, 64), leftH = __shfl_up(h, 1, 64);
-                if (lane == 0) { leftS = carryS; leftH = carryH; }
+                const int leftS = dppWaveShr1(sCell, carryS), leftH = dppWaveShr1(h, carryH);
                 if (valid && j >= 1 && leftH + GEXT >= leftS + GOPEN) tr |= 8;
-                const int lastIncl = __shfl(incl, 63, 64);
+                const int lastIncl = __builtin_amdgcn_readlane(incl, 63);
                 carryScan = lastIncl > carryScan ? lastIncl : carryScan;
-                carryS = __shfl(sCell, 63, 64); carryH = __shfl(h, 63, 64);
+                carryS = __builtin_amdgcn_readlane(sCell, 63); carryH = __builtin_amdgcn_readlane(h, 63);
                 if (valid) { cS[j] = sCell; cV[j] = v; trace[(size_t)i * (n + 1) + j] = (u8)(tr | tb); }
             }
-            waveFence();
+            if (ldsPerWave) waveFenceLds(); else waveFence();      // the rows live in LDS (or in the global slab)
             int * tS = pS; pS = cS; cS = tS; int * tV = pV; pV = cV; cV = tV;
         }
+        waveFence();                                                // the trace is read back from the global slab
         // best cell of the last row (pS), leftmost on ties
         int bs = NEG, bj = -1;
         for (int base = 0; base <= n; base += 64)
@@ -668,11 +666,34 @@ __global__ __launch_bounds__(256) void k_pe_rescue(FinalizeArgs A, PeView V, con
             if (mx > bs) { bs = mx; bj = base + (int)(__ffsll((long long)__ballot(j <= n && val == mx)) - 1); }
         }
         // traceback (uniform), counting gap runs and gap characters of the clipped alignment
+        // The walk is a chain of dependent reads of the trace in the global slab (~2 us each: it was most of this kernel's time).  So 64 rows
+        // are fetched at once: lane L holds the 8 cells of row rowHi - L around the diagonal through the current cell, and the walk reads
+        // them with v_readlane; a path that leaves the 8-cell corridor (a long gap) or the 64 rows refetches.
         int i = m, j = bj, state = 0, lastOp = -1;
         u32 gapOpens = 0, gapChars = 0;
+        const bool corridor = n + 1 >= 8;
+        int rowHi = -1, jHi = 0; u32 cellsLo = 0, cellsHi = 0;
+        auto corridorStart = [&](int row) -> int { int c = jHi - (rowHi - row) - 4; if (c < 0) c = 0; if (c > n + 1 - 8) c = n + 1 - 8; return c; };
         while (i > 0)
         {
-            const u8 tr = trace[(size_t)i * (n + 1) + j];
+            u8 tr;
+            if (corridor)
+            {
+                int c0 = rowHi >= 0 ? corridorStart(i) : 0;
+                if (rowHi < 0 || i > rowHi || rowHi - i > 63 || j < c0 || j >= c0 + 8)
+                {
+                    rowHi = i; jHi = j;
+                    const int row = i - (int)lane;
+                    u64 cells = 0;
+                    if (row >= 0) cells = load8(trace + (size_t)row * (n + 1) + corridorStart(row));
+                    cellsLo = (u32)cells; cellsHi = (u32)(cells >> 32);
+                    c0 = corridorStart(i);
+                }
+                const int L = __builtin_amdgcn_readfirstlane(rowHi - i), at = __builtin_amdgcn_readfirstlane(j - c0);
+                const u32 word = at < 4 ? (u32)__builtin_amdgcn_readlane((int)cellsLo, L) : (u32)__builtin_amdgcn_readlane((int)cellsHi, L);
+                tr = (u8)(word >> (8 * (at & 3)));
+            }
+            else tr = trace[(size_t)i * (n + 1) + j];
             int op;
             if (state == 0)
             {
