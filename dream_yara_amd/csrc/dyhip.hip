@@ -398,6 +398,19 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
             ctx->scanTmp.reserve(tmpBytes + 64);
             HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nReads + 1), st));
             HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nReads, 4, hipMemcpyDeviceToHost, st));
+            if ((u64)nReads * nBins > 0x7FFFFFFFull)
+            {   // the list is indexed with 31 bits and the 32-bit scan could have wrapped (every read selecting hundreds of bins: an unfiltered
+                // run over many bins): count again in 64 bits
+                ctx->binTotals.reserve(16);
+                size_t rb = 0;
+                HIP_CHECK(hipcub::DeviceReduce::Sum(nullptr, rb, ctx->waveCounts.as<u32>(), ctx->binTotals.as<unsigned long long>(), (int)nReads, st));
+                ctx->scanTmp.reserve(rb + 64);
+                HIP_CHECK(hipcub::DeviceReduce::Sum(ctx->scanTmp.p, rb, ctx->waveCounts.as<u32>(), ctx->binTotals.as<unsigned long long>(), (int)nReads, st));
+                unsigned long long exact = 0;
+                HIP_CHECK(hipMemcpyAsync(&exact, ctx->binTotals.p, 8, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (exact > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "more than 2^31 (read, bin) pairs in one batch: map fewer reads per batch");
+            }
             HIP_CHECK(hipStreamSynchronize(st));
             collectSweepTime(ctx, reads);
             ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
