@@ -226,11 +226,7 @@ int main(int argc, char ** argv)
             {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
                 ReadsBatch second;
                 if (in2->next(second, batch.size(), hostThreads) != batch.size()) fail("the two reads files hold different numbers of records");
-                const u64 shift = batch.codes.size();
-                batch.names.insert(batch.names.end(), second.names.begin(), second.names.end());
-                batch.codes.insert(batch.codes.end(), second.codes.begin(), second.codes.end());
-                batch.quals.insert(batch.quals.end(), second.quals.begin(), second.quals.end());
-                for (size_t i = 1; i < second.offs.size(); ++i) batch.offs.push_back(second.offs[i] + shift);
+                batch.append(second);
             }
             sl.nPairs = batch.size() / 2;
             return true;
@@ -268,9 +264,9 @@ int main(int argc, char ** argv)
                 const dy_read_result & r = rr[j];
                 a.flag = 0; a.rid = a.pos = -1; a.mapq = 0; a.cigar = nullptr; a.nCigar = 0; a.rnext = a.pnext = -1; a.tlen = 0;
                 a.hasCounts = false; a.nm = a.x0 = a.x1 = 0; a.xa.clear();
-                const std::string & name = batch.names[i];
-                size_t cut = name.find_first_of(" \t/");
-                a.qname.assign(name, 0, cut == std::string::npos ? name.size() : cut);
+                const std::string_view name = batch.name(i);
+                const size_t cut = name.find_first_of(" \t/");
+                a.qname.assign(name.data(), cut == std::string_view::npos ? name.size() : cut);
                 const u8 * codes = batch.codes.data() + batch.offs[i];
                 const char * quals = batch.quals.data() + batch.offs[i];
                 const size_t len = (size_t)(batch.offs[i + 1] - batch.offs[i]);

@@ -3,6 +3,8 @@
 // uploaded to HBM (see DESIGN.md "Data layout").  File formats: SURVEY.md Appendix A; producer side in the
 // reference: src/index_fm.h:68-82, src/store_seqs.h:143-158, src/misc_options.h:293-307, src/d_bloom_filter.h:150-154.
 #pragma once
+#include <string_view>
+#include <atomic>
 #include "dy_types.h"
 #include <string>
 #include <vector>
@@ -45,6 +47,16 @@ public:
     MappedFile & operator=(const MappedFile &) = delete;
     const u8 * data() const { return (const u8 *)ptr_; }
     size_t size() const { return size_; }
+    // Maps the pages of [p, p + len) in one call (MADV_POPULATE_READ, Linux 5.14+; ignored where unknown): a first touch per 4 KB page
+    // costs a sequential parser more than the parsing
+    void populate(const u8 * p, size_t len) const
+    {
+        if (!ptr_ || ptr_ == MAP_FAILED || !len || p < data() || p >= data() + size_) return;
+        const size_t page = 4096;
+        const size_t lo = (size_t)(p - data()) & ~(page - 1);
+        size_t hi = (size_t)(p - data()) + len; if (hi > size_) hi = size_;
+        (void)madvise((u8 *)ptr_ + lo, hi - lo, 22 /* MADV_POPULATE_READ */);
+    }
 private:
     int fd_ = -1; void * ptr_ = nullptr; size_t size_ = 0;
 };
@@ -217,12 +229,26 @@ inline u8 dna5Code(char c)
 // Streaming FASTA/FASTQ reader producing SoA batches (codes + offsets) ready for dy_reads_upload.
 struct ReadsBatch
 {
-    std::vector<std::string> names;
-    std::vector<u8>  codes;     // forward reads back to back
-    std::vector<u64> offs;      // n+1
-    std::vector<char> quals;    // same layout as codes; 'I' for FASTA, '!' under N
-    size_t size() const { return names.size(); }
-    void clear() { names.clear(); codes.clear(); offs.assign(1, 0); quals.clear(); }
+    std::vector<char> nameChars;   // read names back to back (one allocation per batch, not one per read)
+    std::vector<u64> nameOffs;     // n+1
+    std::vector<u8>  codes;        // forward reads back to back
+    std::vector<u64> offs;         // n+1
+    std::vector<char> quals;       // same layout as codes; 'I' for FASTA, '!' under N
+    size_t size() const { return nameOffs.size() - 1; }
+    std::string_view name(size_t i) const { return std::string_view(nameChars.data() + nameOffs[i], (size_t)(nameOffs[i + 1] - nameOffs[i])); }
+    // (the byte arrays keep their size: the reader resizes them to the batch's exact totals, and a clear() + resize() would zero-fill
+    // a few hundred MB per batch for nothing)
+    void clear() { nameOffs.assign(1, 0); offs.assign(1, 0); }
+    // the reads of `other` behind these (file pairs: first mates, then second mates)
+    void append(const ReadsBatch & other)
+    {
+        const u64 nameShift = nameChars.size(), baseShift = codes.size();
+        nameChars.insert(nameChars.end(), other.nameChars.begin(), other.nameChars.end());
+        codes.insert(codes.end(), other.codes.begin(), other.codes.end());
+        quals.insert(quals.end(), other.quals.begin(), other.quals.end());
+        for (size_t i = 1; i < other.nameOffs.size(); ++i) nameOffs.push_back(other.nameOffs[i] + nameShift);
+        for (size_t i = 1; i < other.offs.size(); ++i) offs.push_back(other.offs[i] + baseShift);
+    }
 };
 
 class ReadsFile
@@ -254,51 +280,64 @@ public:
         else if (map_.size() >= 3 && map_.data()[0] == 'B' && map_.data()[1] == 'Z' && map_.data()[2] == 'h')
             throw IoError("bzip2-compressed input is not supported (no libbz2 on this system)");
     }
-    // Reads up to maxReads records into b; returns their number.  Two phases over byte spans of the mapped file (no temporaries):
-    // a sequential pass finds the record boundaries (one memchr per line) and the offsets, then `threads` workers convert disjoint
-    // record ranges (256-entry table for the bases) into the pre-sized arrays.
+    // Reads up to maxReads records into b; returns their number.  Byte spans of the mapped file, no temporaries:
+    //   * four-line FASTQ (the usual case) with several threads: the threads index the line ends of a window sized from the previous
+    //     batch, every record is then lines 4r .. 4r+3 — checked ('@' / '+' markers) — and the threads convert disjoint record ranges;
+    //     anything unexpected (blank lines, wrapped sequences, a window that holds too few lines) falls back to
+    //   * the general form: one sequential pass finds the record boundaries (a memchr per line; wrapped FASTA, blank lines), then the
+    //     threads convert.
     size_t next(ReadsBatch & b, size_t maxReads, unsigned threads = 1)
     {
         b.clear();
         spans_.clear();
-        size_t bases = 0;
-        while (spans_.size() < maxReads)
+        skipBlank();
+        if (p_ >= end_ || maxReads == 0) { b.nameChars.clear(); b.codes.clear(); b.quals.clear(); return 0; }
+        if (*p_ != '>' && *p_ != '@') throw IoError("unrecognised reads file format");
+        map_.populate(p_, bytesPerRecord_ > 0 ? (size_t)(bytesPerRecord_ * (double)maxReads * 1.05) + 65536 : (size_t)64 << 20);
+        if (!(threads > 1 && *p_ == '@' && bytesPerRecord_ > 0 && indexFastqWindow(maxReads, threads)))
         {
-            skipBlank();
-            if (p_ >= end_) break;
-            const char marker = (char)*p_;
-            if (marker != '>' && marker != '@') throw IoError("unrecognised reads file format");
-            RecSpan r;
-            const u8 * s, * e;
-            span(s, e);
-            r.nameS = s + 1; r.nameE = e;
-            r.fasta = marker == '>';
-            r.len = 0;
-            if (r.fasta)
-            {   // the sequence may span several lines: remember the region, count the bases
-                r.seqS = p_;
-                while (p_ < end_ && *p_ != '>') { span(s, e); r.len += (size_t)(e - s); }
-                r.seqE = p_;
-                r.qualS = r.qualE = nullptr;
-            }
-            else
+            const u8 * first = p_;
+            while (spans_.size() < maxReads)
             {
-                span(s, e); r.seqS = s; r.seqE = e; r.len = (size_t)(e - s);
-                span(s, e);                               // '+'
-                span(s, e); r.qualS = s; r.qualE = e;
+                skipBlank();
+                if (p_ >= end_) break;
+                const char marker = (char)*p_;
+                if (marker != '>' && marker != '@') throw IoError("unrecognised reads file format");
+                RecSpan r;
+                const u8 * s, * e;
+                span(s, e);
+                r.nameS = s + 1; r.nameE = e;
+                r.fasta = marker == '>';
+                r.len = 0;
+                if (r.fasta)
+                {   // the sequence may span several lines: remember the region, count the bases
+                    r.seqS = p_;
+                    while (p_ < end_ && *p_ != '>') { span(s, e); r.len += (size_t)(e - s); }
+                    r.seqE = p_;
+                    r.qualS = r.qualE = nullptr;
+                }
+                else
+                {
+                    span(s, e); r.seqS = s; r.seqE = e; r.len = (size_t)(e - s);
+                    span(s, e);                               // '+'
+                    span(s, e); r.qualS = s; r.qualE = e;
+                }
+                spans_.push_back(r);
             }
-            bases += r.len;
-            b.offs.push_back(bases);
-            spans_.push_back(r);
+            if (!spans_.empty()) bytesPerRecord_ = (double)(p_ - first) / (double)spans_.size();
         }
         const size_t n = spans_.size();
-        b.names.resize(n); b.codes.resize(bases); b.quals.resize(bases);
+        b.offs.resize(n + 1); b.nameOffs.resize(n + 1);
+        u64 bases = 0, nameBytes = 0;
+        for (size_t i = 0; i < n; ++i) { b.offs[i] = bases; b.nameOffs[i] = nameBytes; bases += spans_[i].len; nameBytes += (u64)(spans_[i].nameE - spans_[i].nameS); }
+        b.offs[n] = bases; b.nameOffs[n] = nameBytes;
+        b.nameChars.resize(nameBytes); b.codes.resize(bases); b.quals.resize(bases);
         auto convert = [&](size_t lo, size_t hi) {
             static const Dna5Table lut;
             for (size_t i = lo; i < hi; ++i)
             {
                 const RecSpan & r = spans_[i];
-                b.names[i].assign((const char *)r.nameS, (const char *)r.nameE);
+                memcpy(b.nameChars.data() + b.nameOffs[i], r.nameS, (size_t)(r.nameE - r.nameS));
                 u8 * codes = b.codes.data() + b.offs[i];
                 char * quals = b.quals.data() + b.offs[i];
                 if (r.fasta)
@@ -316,12 +355,15 @@ public:
                     for (size_t k = 0; k < r.len; ++k) quals[k] = codes[k] == 4 ? '!' : 'I';
                 }
                 else
-                {
+                {   // one pass: code, quality clamped to 6 bits (Dna5Q), '!' under N (N carries no quality), 'I' where the quality line is short
                     const size_t ql = std::min(r.len, (size_t)(r.qualE - r.qualS));
-                    for (size_t k = 0; k < r.len; ++k) codes[k] = lut.code[r.seqS[k]];
-                    for (size_t k = 0; k < ql; ++k) quals[k] = (char)(r.qualS[k] > 33 + 62 ? 33 + 62 : r.qualS[k]);   // Dna5Q keeps 6 quality bits
-                    for (size_t k = ql; k < r.len; ++k) quals[k] = 'I';
-                    for (size_t k = 0; k < r.len; ++k) if (codes[k] == 4) quals[k] = '!';                               // N carries no quality
+                    for (size_t k = 0; k < ql; ++k)
+                    {
+                        const u8 c = lut.code[r.seqS[k]], q = r.qualS[k];
+                        codes[k] = c;
+                        quals[k] = c == 4 ? '!' : (char)(q > 33 + 62 ? 33 + 62 : q);
+                    }
+                    for (size_t k = ql; k < r.len; ++k) { const u8 c = lut.code[r.seqS[k]]; codes[k] = c; quals[k] = c == 4 ? '!' : 'I'; }
                 }
             }
         };
@@ -338,6 +380,7 @@ public:
     }
 private:
     struct Dna5Table { u8 code[256]; Dna5Table() { for (int c = 0; c < 256; ++c) code[c] = dna5Code((char)c); } };
+    struct RecSpan { const u8 * nameS, * nameE, * seqS, * seqE, * qualS, * qualE; size_t len; bool fasta; };
     void skipBlank() { while (p_ < end_ && (*p_ == '\n' || *p_ == '\r')) ++p_; }
     // [s, e) = the next line without its terminator and trailing CR / blanks
     void span(const u8 *& s, const u8 *& e)
@@ -348,8 +391,91 @@ private:
         p_ = nl ? nl + 1 : end_;
         while (e > s && (e[-1] == '\r' || e[-1] == ' ')) --e;
     }
-    struct RecSpan { const u8 * nameS, * nameE, * seqS, * seqE, * qualS, * qualE; size_t len; bool fasta; };
+    // Four-line FASTQ, threaded: fills spans_ with up to maxReads records starting at p_ and advances p_, or leaves both untouched and
+    // returns false (the caller then takes the general path from the same position).
+    bool indexFastqWindow(size_t maxReads, unsigned threads)
+    {
+        const size_t remaining = (size_t)(end_ - p_);
+        size_t window = (size_t)(bytesPerRecord_ * (double)maxReads * 1.02) + 4096;
+        for (int attempt = 0; attempt < 2; ++attempt, window += window / 3)      // records longer than the previous batch's: one wider try
+            if (indexFastqWindow(maxReads, threads, std::min(window, remaining))) return true;
+        return false;
+    }
+    bool indexFastqWindow(size_t maxReads, unsigned threads, size_t window)
+    {
+        const size_t remaining = (size_t)(end_ - p_);
+        const u8 * base = p_;
+        // line ends of the window, chunk by chunk
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, window / (1 << 20) + 1));
+        std::vector<std::vector<u32> > ends(T);
+        if (window > 0xFFFFFFF0ull) return false;
+        auto scan = [&](unsigned t) {
+            const size_t lo = window * t / T, hi = window * (t + 1) / T;
+            std::vector<u32> & v = ends[t];
+            v.reserve((hi - lo) / 48 + 16);
+            const u8 * q = base + lo, * stop = base + hi;
+            while (q < stop)
+            {
+                const u8 * nl = (const u8 *)memchr(q, '\n', (size_t)(stop - q));
+                if (!nl) break;
+                v.push_back((u32)(nl - base));
+                q = nl + 1;
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; ++t) pool.emplace_back(scan, t);
+            scan(0);
+            for (auto & th : pool) th.join();
+        }
+        size_t nLines = 0;
+        for (auto & v : ends) nLines += v.size();
+        const bool atEof = window == remaining;
+        const bool tail = atEof && window > 0 && base[window - 1] != '\n';       // a last line without its newline
+        size_t nRec = (nLines + (tail ? 1 : 0)) / 4;
+        if (nRec > maxReads) nRec = maxReads;
+        if (nRec == 0 || (nRec < maxReads && !atEof)) return false;                 // the window came out too small: general path
+        lineEnds_.resize(nRec * 4);
+        {
+            size_t at = 0;
+            for (auto & v : ends) for (u32 e : v) { if (at == nRec * 4) break; lineEnds_[at++] = e; }
+            if (at < nRec * 4) lineEnds_[at++] = (u32)window;                        // the unterminated last line
+            if (at < nRec * 4) return false;
+        }
+        spans_.resize(nRec);
+        std::atomic<bool> ok(true);
+        auto build = [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; ++r)
+            {
+                const u8 * l0 = base + (r ? lineEnds_[4 * r - 1] + 1 : 0);
+                const u8 * e0 = base + lineEnds_[4 * r], * e1 = base + lineEnds_[4 * r + 1], * e2 = base + lineEnds_[4 * r + 2], * e3 = base + lineEnds_[4 * r + 3];
+                const u8 * l1 = e0 + 1, * l2 = e1 + 1, * l3 = e2 + 1;
+                if (l0 >= e0 || *l0 != '@' || l2 > e2 || (l2 < e2 ? *l2 != '+' : true) || l1 > e1) { ok = false; return; }
+                auto trim = [](const u8 * s, const u8 * e) { while (e > s && (e[-1] == '\r' || e[-1] == ' ')) --e; return e; };
+                RecSpan & R = spans_[r];
+                R.nameS = l0 + 1; R.nameE = trim(l0 + 1, e0);
+                R.seqS = l1; R.seqE = trim(l1, e1); R.len = (size_t)(R.seqE - R.seqS);
+                R.qualS = l3; R.qualE = trim(l3, e3);
+                R.fasta = false;
+                if (R.len == 0) { ok = false; return; }                              // a blank line where the sequence should be: not this layout
+            }
+        };
+        {
+            const unsigned TB = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, nRec / 8192 + 1));
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < TB; ++t) pool.emplace_back(build, nRec * t / TB, nRec * (t + 1) / TB);
+            build(0, nRec / TB);
+            for (auto & th : pool) th.join();
+        }
+        if (!ok) { spans_.clear(); return false; }
+        const size_t used = (size_t)lineEnds_[nRec * 4 - 1] + 1;
+        p_ = base + (used < window ? used : window);
+        bytesPerRecord_ = (double)(p_ - base) / (double)nRec;
+        return true;
+    }
     std::vector<RecSpan> spans_;
+    std::vector<u32> lineEnds_;
+    double bytesPerRecord_ = 0;        // of the previous batch: sizes the window of the threaded FASTQ path
     MappedFile map_;
     std::vector<u8> inflated_;
     const u8 * p_; const u8 * end_;

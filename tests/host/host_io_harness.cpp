@@ -3,6 +3,7 @@
 //   host_io_harness write <out.sam> <out.bam> <n> <threads> -> the same n synthetic records as SAM text and as BGZF BAM
 #include "../../dream_yara_amd/csrc/host_formats.hpp"
 #include "../../dream_yara_amd/csrc/bam_writer.hpp"
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <random>
@@ -28,10 +29,27 @@ int main(int argc, char ** argv)
                 {
                     std::string seq, qual;
                     for (u64 p = b.offs[i]; p < b.offs[i + 1]; ++p) { seq += "ACGTN"[b.codes[p]]; qual += b.quals[p]; }
-                    std::cout << b.names[i] << '\t' << seq << '\t' << qual << '\n';
+                    std::cout << b.name(i) << '\t' << seq << '\t' << qual << '\n';
                 }
             }
             std::cerr << batches << " batches\n";
+            return 0;
+        }
+        if (mode == "parsebench" && argc == 5)
+        {   // host_io_harness parsebench <reads file> <max per batch> <threads>: time of the parse alone, and a checksum of what it produced
+            ReadsFile in(argv[2]);
+            ReadsBatch b;
+            const size_t per = std::stoul(argv[3]);
+            const unsigned threads = (unsigned)std::stoul(argv[4]);
+            size_t reads = 0; u64 sum = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (in.next(b, per, threads))
+            {
+                reads += b.size();
+                sum += b.offs.back() * 31 + b.name(b.size() - 1).size() + b.codes[b.codes.size() / 2] + (u64)b.quals[b.quals.size() / 3];
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::cout << reads << " reads in " << dt << " s = " << reads / dt / 1e6 << " M reads/s, checksum " << sum << "\n";
             return 0;
         }
         if (mode == "write" && argc == 6)

@@ -56,6 +56,33 @@ def test_threaded_parse_equals_sequential_parse(harness, tmp_path):
         assert subprocess.check_output([harness, "parse", str(path), "17000", "3"]) == one      # several batches
 
 
+def test_threaded_fastq_path_falls_back_on_irregular_records(harness, tmp_path):
+    """The threaded four-line FASTQ path (line index of a window sized from the previous batch) must give the sequential parser's
+    batches whatever it meets: blank lines between records, CRLF, '+name' separator lines, reads much longer than the previous
+    batch's (window too small), a quality line starting with '@', a last record without its newline."""
+    import random
+    rnd = random.Random(11)
+    path = tmp_path / "odd.fq"
+    with open(path, "wb") as f:
+        def rec(i, L, eol=b"\n", plus=b"+", blank=False):
+            seq = bytes(rnd.choice(b"ACGTN" if rnd.random() < 0.02 else b"ACGT") for _ in range(L))
+            qual = bytes(rnd.randint(33, 126) for _ in range(L))
+            if i % 97 == 0: qual = b"@" + qual[1:]
+            out = b"@odd_%d extra words/1" % i + eol + seq + eol + plus + eol + qual + eol
+            return (b"\n" if blank else b"") + out
+        for i in range(12000): f.write(rec(i, rnd.randint(30, 60)))
+        for i in range(12000, 15000): f.write(rec(i, rnd.randint(30, 60), eol=b"\r\n"))
+        for i in range(15000, 18000): f.write(rec(i, rnd.randint(30, 60), plus=b"+odd_%d" % i))
+        for i in range(18000, 21000): f.write(rec(i, rnd.randint(30, 60), blank=(i % 500 == 0)))
+        for i in range(21000, 26000): f.write(rec(i, rnd.randint(200, 400)))                  # the window of the previous batch is too small
+        for i in range(26000, 30000): f.write(rec(i, rnd.randint(30, 60)))
+        f.write(rec(30000, 40)[:-1])                                                             # no newline at the end of the file
+    one = subprocess.check_output([harness, "parse", str(path), "1000000", "1"])
+    assert one.count(b"\n") == 30001
+    for per, threads in ((2500, 4), (999, 3), (7000, 8), (1000000, 5)):
+        assert subprocess.check_output([harness, "parse", str(path), str(per), str(threads)]) == one
+
+
 @pytest.mark.parametrize("n,threads", [(0, 1), (50, 1), (4000, 4)])
 def test_bam_stream_decodes_to_the_sam_text(harness, tmp_path, n, threads):
     sam, bam = str(tmp_path / "o.sam"), str(tmp_path / "o.bam")
