@@ -321,10 +321,13 @@ int main(int argc, char ** argv)
                 nMapped += r.mapped;
             }
         };
-        auto formatAndWrite = [&](Slot & sl) {
+        // A batch's records are formatted by the host threads into chunks (in output order), then written by one thread while the next
+        // batch is being formatted.
+        struct Chunk { const Part * pt; size_t jlo, jhi; std::string sam; std::vector<uint8_t> bam; unsigned long long nMapped = 0; };
+        struct Formatted { std::vector<Chunk> chunks; unsigned long long reads = 0; };
+        auto formatSlot = [&](Slot & sl, Formatted & out) {
             // output order = input order: the first mates of every part, then the second mates of every part (single-end: one pass)
-            struct Chunk { const Part * pt; size_t jlo, jhi; std::string sam; std::vector<uint8_t> bam; unsigned long long nMapped = 0; };
-            std::vector<Chunk> chunks;
+            const size_t first = out.chunks.size();
             const unsigned passes = opt.params.paired ? 2 : 1;
             for (unsigned pass = 0; pass < passes; ++pass)
                 for (const Part & pt : sl.parts)
@@ -332,30 +335,33 @@ int main(int argc, char ** argv)
                     const size_t np = pt.hi - pt.lo;
                     const size_t base = pass * np;
                     const size_t pieces = std::max<size_t>(1, std::min<size_t>(hostThreads, np / 4096 + 1));
-                    for (size_t c = 0; c < pieces; ++c) { Chunk ch; ch.pt = &pt; ch.jlo = base + np * c / pieces; ch.jhi = base + np * (c + 1) / pieces; chunks.push_back(std::move(ch)); }
+                    for (size_t c = 0; c < pieces; ++c) { Chunk ch; ch.pt = &pt; ch.jlo = base + np * c / pieces; ch.jhi = base + np * (c + 1) / pieces; out.chunks.push_back(std::move(ch)); }
                 }
             const auto f0 = now();
             {
-                std::atomic<size_t> next(0);
-                auto work = [&] { for (;;) { const size_t c = next.fetch_add(1); if (c >= chunks.size()) break; Chunk & ch = chunks[c]; formatRange(sl, *ch.pt, ch.jlo, ch.jhi, ch.sam, ch.bam, ch.nMapped); } };
-                const unsigned T = (unsigned)std::min<size_t>(hostThreads, chunks.size());
+                std::atomic<size_t> next(first);
+                auto work = [&] { for (;;) { const size_t c = next.fetch_add(1); if (c >= out.chunks.size()) break; Chunk & ch = out.chunks[c]; formatRange(sl, *ch.pt, ch.jlo, ch.jhi, ch.sam, ch.bam, ch.nMapped); } };
+                const unsigned T = (unsigned)std::min<size_t>(hostThreads, out.chunks.size() - first);
                 std::vector<std::thread> pool;
                 for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
                 work();
                 for (auto & th : pool) th.join();
             }
             formatSeconds += since(f0);
+            out.reads += sl.batch.size();
+        };
+        auto formatRound = [&](Round & rd) { Formatted f; for (size_t i = 0; i < rd.used; ++i) formatSlot(rd.slots[i], f); return f; };
+        auto writeFormatted = [&](Formatted f) {
             const auto w0 = now();
-            for (Chunk & ch : chunks)
+            for (Chunk & ch : f.chunks)
             {
                 if (bam) bgzf.writeParallel(ch.bam.data(), ch.bam.size(), hostThreads);
                 else os.write(ch.sam.data(), (std::streamsize)ch.sam.size());
                 mapped += ch.nMapped;
             }
-            total += sl.batch.size();
+            total += f.reads;
             writeSeconds += since(w0);
         };
-        auto writeRound = [&](Round & rd) { for (size_t i = 0; i < rd.used; ++i) formatAndWrite(rd.slots[i]); };
         auto releaseRound = [&](Round & rd) {          // device objects go back while no thread drives the contexts
             for (size_t i = 0; i < rd.used; ++i)
                 for (Part & pt : rd.slots[i].parts)
@@ -435,23 +441,33 @@ int main(int argc, char ** argv)
             }
             mapSeconds += since(m0);
         };
-        std::future<void> writer;                // at most one: keeps the output in input order
-        int writing = -1;
+        // Four stages in flight: one round being parsed, one on the devices, one being formatted, one being written (in input order: at
+        // most one formatter and one writer at a time).  A round's device objects go back when its records are formatted.
+        std::future<Formatted> formatter;
+        std::future<void> writer;
+        int formatting = -1;
+        auto retireFormatter = [&] {
+            Formatted f = formatter.get();
+            releaseRound(rounds[formatting]); formatting = -1;
+            if (writer.valid()) writer.get();
+            writer = std::async(std::launch::async, [&writeFormatted, f = std::move(f)]() mutable { writeFormatted(std::move(f)); });
+        };
         int cur = 0;
         bool have = readRound(rounds[cur]);
         while (have)
         {
             const int nxt = (cur + 1) % 3;
-            if (writing == nxt) { writer.get(); releaseRound(rounds[nxt]); writing = -1; }      // the round about to be refilled must be written out
+            if (formatting == nxt) retireFormatter();                                   // the round about to be refilled must be formatted
             std::future<bool> reader = std::async(std::launch::async, [&, nxt] { return readRound(rounds[nxt]); });
             mapRound(rounds[cur]);
-            if (writing >= 0) { writer.get(); releaseRound(rounds[writing]); writing = -1; }
-            writer = std::async(std::launch::async, [&, cur] { writeRound(rounds[cur]); });
-            writing = cur;
+            if (formatting >= 0) retireFormatter();
+            formatter = std::async(std::launch::async, [&, cur] { return formatRound(rounds[cur]); });
+            formatting = cur;
             have = reader.get();
             cur = nxt;
         }
-        if (writing >= 0) { writer.get(); releaseRound(rounds[writing]); }
+        if (formatting >= 0) retireFormatter();
+        if (writer.valid()) writer.get();
         if (bam) bgzf.finish();
         os.flush();
         if (opt.verbose)
