@@ -121,21 +121,34 @@ def compare_all_fields(dev, ora):
     return bad
 
 
-def cpu_baseline(wl, idx_dir, oibf, codes, offs, error_rate, sample_reads):
+def first_pairs(codes, offs, k):
+    """The first k pairs of a paired batch ([first mates | second mates]) as a paired batch of 2k reads."""
+    P = (offs.size - 1) // 2
+    lens = np.diff(offs).astype(np.uint64)
+    sel = np.concatenate([np.arange(0, k), np.arange(P, P + k)])
+    parts = [codes[int(offs[i]):int(offs[i + 1])] for i in sel]
+    o = np.zeros(2 * k + 1, np.uint64); o[1:] = np.cumsum(lens[sel])
+    return np.concatenate(parts), o
+
+
+def cpu_baseline(wl, idx_dir, oibf, codes, offs, error_rate, sample_reads, paired=False):
     """Oracle (CPU restatement of the reference path, kind 'port') on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     n = min(sample_reads, offs.size - 1)
+    if paired:
+        n = offs.size - 1               # a paired batch is [first mates | second mates]: the whole batch, so that it doubles as the parity check
     oidx = ob.OracleIndex(idx_dir, wl["bins"])
     t0 = time.time()
-    res = ob.map_batch(oidx, oibf, codes[: int(offs[n])], offs[: n + 1], error_rate, threads=threads)
+    res = ob.map_batch(oidx, oibf, codes[: int(offs[n])], offs[: n + 1], error_rate, threads=threads, paired=paired)
     dt = time.time() - t0
     # the same restatement on ONE thread, on a smaller slice of the same batch (SURVEY.md §8d asks for both figures)
     n1 = min(n, 200000)
+    c1, o1 = (codes[: int(offs[n1])], offs[: n1 + 1]) if not paired else first_pairs(codes, offs, n1 // 2)
     t1 = time.time()
-    ob.map_batch(oidx, oibf, codes[: int(offs[n1])], offs[: n1 + 1], error_rate, threads=1)
+    ob.map_batch(oidx, oibf, c1, o1, error_rate, threads=1, paired=paired)
     dt1 = time.time() - t1
     oidx.close()
     return {"value": n / dt, "unit": "reads/s", "cores": threads, "host_cores": cores, "host_cpu": cpu_model(), "kind": "port",
@@ -373,7 +386,7 @@ def main():
 
     if rank == 0:
         out = first["line"]
-        if args.cpu_sample > 0 and world == 1 and not args.paired and legs[0] == "reads":
+        if args.cpu_sample > 0 and world == 1 and legs[0] == "reads":
             import subprocess
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -381,7 +394,7 @@ def main():
             words, nb = ibf.words()                      # the oracle reads the very filter the device holds
             oibf = ob.OracleIbf(None, words=words, n_bits=nb)
             codes, offs = host_batch0
-            base, ores = cpu_baseline(wl, idx_dir, oibf, codes, offs, error_rate, args.cpu_sample)
+            base, ores = cpu_baseline(wl, idx_dir, oibf, codes, offs, error_rate, args.cpu_sample, paired=args.paired)
             oibf.close(); del words
             # the sample doubles as a parity check of the timed configuration: every field of every read of the sample
             n = ores[0].size
@@ -389,8 +402,15 @@ def main():
             nm = int(d_reads["set_begin"][n - 1] + d_reads["best_count"][n - 1] + d_reads["sub_count"][n - 1]) if n else 0
             nc = int(d_reads["cigar_begin"][n - 1] + d_reads["cigar_len"][n - 1]) if n else 0
             diff = compare_all_fields((d_reads[:n], d_matches[:nm], d_cigars[:nc]), ores[:3])
+            if args.paired:
+                # the pairing weights: the oracle evaluates them with libm like the reference, the device with its fixed IEEE sequences
+                if not np.array_equal(d_reads["paired"][:n], ores[0]["paired"]):
+                    diff.append("paired")
+                if not np.allclose(d_reads["pair_prob"][:n], ores[0]["pair_prob"], rtol=1e-9, atol=0.0):
+                    diff.append("pair_prob")
             base["parity_with_gpu_on_sample"] = not diff
-            base["parity_fields"] = "mapped, X0, X1, MAPQ, primary (contig, begin, length, errors, strand), matchesSet, CIGARs of the first %d reads" % n
+            base["parity_fields"] = ("mapped, X0, X1, MAPQ, primary (contig, begin, length, errors, strand), matchesSet, CIGARs" +
+                                     (", paired, pair probability (relative 1e-9)" if args.paired else "") + " of the first %d reads" % n)
             if diff:
                 base["parity_differs_in"] = diff
             out["cpu_baseline"] = base
