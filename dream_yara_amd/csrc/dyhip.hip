@@ -125,6 +125,7 @@ struct Tuning
     u64 ibfLdsKb = 12;          // LDS per wave of k_ibf_query_wide
     u64 ibfDense = 0;           // 1 = no sparse verification in k_ibf_query_wide
     u64 ibfKernel = 0;          // sweep for W > 1 and reads of at most 255 k-mers: 0 = by expected false candidates, 1 = k_ibf_query_lazy, 2 = k_ibf_query_eager2, 3 = k_ibf_query_wide
+    u64 ibfOwnStream = 0;       // 1 = dy_ibf_query runs on the context's second stream (a caller may queue the NEXT batch's sweep before mapping the current one)
     u64 ibfSlack = 0;           // first check of the sweeps = nK - threshold + slack k-mers (0 = derived from the filter's fill)
     u64 poolCap = 0;            // initial capacity of the raw-match pool (0 = 2 x items); it grows on overflow either way
     u64 dpSmallBlocks = 4096;   // grid of the thread-level aggregation kernels (k_finalize_small, k_pe_*): list-driven, grid-stride
@@ -834,7 +835,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
-            {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255},
+            {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255}, {"ibf_own_stream", &t.ibfOwnStream, 0, 1},
             {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1},
         };
         for (auto & k : keys)
@@ -1041,7 +1042,7 @@ int dy_ibf_get_info(const dy_ibf * f, dy_ibf_info * info)
     return DY_OK;
 }
 
-void dy_ibf_free(dy_ibf * f) { if (f) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->ibfStream); delete f; } }
+void dy_ibf_free(dy_ibf * f) { if (f) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->ibfStream); (void)hipStreamSynchronize(f->ctx->stream); delete f; } }
 
 uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len)
 {
@@ -1141,10 +1142,16 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         // gets the two overlapped (dy_map_reads makes the main stream wait for the batch's own sweep).  Everything this call reads was
         // put in place by synchronous calls (dy_reads_upload, dy_ibf_load / add), so no wait is needed here — except for a mapping that
         // may still be reading the previous masks of the SAME reads object on the main stream.
-        hipStream_t sq = ctx->ibfStream;
+        // (tuning key ibf_own_stream; off by default: the hand-over between two streams costs ~25 us per batch, and a sweep that already
+        // holds every wave slot overlaps with nothing — DESIGN.md section 8)
+        const bool ownStream = ctx->tune.ibfOwnStream != 0;
+        hipStream_t sq = ownStream ? ctx->ibfStream : ctx->stream;
         for (auto & e : reads->evK1) if (!e) HIP_CHECK(hipEventCreate(&e));
-        HIP_CHECK(hipEventRecord(ctx->evFork, ctx->stream));
-        HIP_CHECK(hipStreamWaitEvent(sq, ctx->evFork, 0));
+        if (ownStream)
+        {
+            HIP_CHECK(hipEventRecord(ctx->evFork, ctx->stream));
+            HIP_CHECK(hipStreamWaitEvent(sq, ctx->evFork, 0));
+        }
         if (reads->n)
         {
             HIP_CHECK(hipEventRecord(reads->evK1[0], sq));

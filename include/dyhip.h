@@ -54,7 +54,8 @@ void       *dy_ctx_stream(dy_ctx *ctx);
  * Keys (value range, default): sparse_sa (0-1, 0), prefix_q (0-12, 12), no_isa (0-1, 0) — read by dy_index_load;
  * finalize_block_min (>=1, 2048), finalize_no_keys (0-1, 0), pe_heavy_min (>=1, 256), pe_rescue_global (0-1, 0),
  * ibf_narrow (0-1, 0), ibf_full_tail (0-1, 0), ibf_lds_kb (4-60, 12), ibf_dense (0-1, 0), ibf_kernel (0-3, 0: sweep for more than 64 bins chosen from the filter fill; 1 lazy, 2 eager2, 3 wide),
- * ibf_slack (0-255, 0 = from the fill), dp_small_blocks (64-65536, 4096) and dp_align_blocks (64-65536, 8192: grids of the
+ * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next
+ * batch's sweep can be queued before the current batch is mapped), dp_small_blocks (64-65536, 4096) and dp_align_blocks (64-65536, 8192: grids of the
  * thread-level aggregation / alignment kernels), items_sorted (0-1, 1: work list as (bin, read) pairs + stable radix sort; 0 = bin-major
  * count matrix), pool_cap (initial raw-match
  * pool capacity, 0 = automatic; the pool grows and the extension is re-run on overflow).  Stands where the reference has
