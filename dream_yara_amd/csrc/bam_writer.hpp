@@ -19,7 +19,7 @@ namespace dy {
 class BgzfWriter
 {
 public:
-    explicit BgzfWriter(std::ostream & os) : os_(os) { buf_.reserve(kBlock); }
+    explicit BgzfWriter(std::ostream & os, int level = -1) : os_(os), level_(level) { buf_.reserve(kBlock); }      // level: zlib's 0..9, -1 = its default (6)
     void write(const void * data, size_t n)
     {
         const uint8_t * p = (const uint8_t *)data;
@@ -44,7 +44,7 @@ public:
         std::vector<std::string> errors(T);
         for (unsigned t = 0; t < T; ++t)
             pool.emplace_back([&, t] {
-                try { for (size_t b = t; b < nBlocks; b += T) compressBlock(data + b * kBlock, kBlock, outBlocks[b]); }
+                try { for (size_t b = t; b < nBlocks; b += T) compressBlock(data + b * kBlock, kBlock, outBlocks[b], level_); }
                 catch (std::exception const & e) { errors[t] = e.what(); }
             });
         for (auto & th : pool) th.join();
@@ -61,11 +61,11 @@ public:
     }
 private:
     static constexpr size_t kBlock = 0xff00;       // payload per block, leaves room for incompressible data
-    static void compressBlock(const uint8_t * in, size_t n, std::vector<uint8_t> & out)
+    static void compressBlock(const uint8_t * in, size_t n, std::vector<uint8_t> & out, int level)
     {
         out.resize(0x10000 + 64);
         z_stream zs; memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib: deflateInit2 failed");
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("zlib: deflateInit2 failed");
         zs.next_in = const_cast<uint8_t *>(in); zs.avail_in = (uInt)n;
         zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 18 - 8);
         if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw std::runtime_error("zlib: deflate failed"); }
@@ -82,11 +82,12 @@ private:
     void flushBlock()
     {
         std::vector<uint8_t> out;
-        compressBlock(buf_.data(), buf_.size(), out);
+        compressBlock(buf_.data(), buf_.size(), out, level_);
         os_.write((const char *)out.data(), (std::streamsize)out.size());
         buf_.clear();
     }
     std::ostream & os_;
+    int level_ = -1;
     std::vector<uint8_t> buf_;
 };
 

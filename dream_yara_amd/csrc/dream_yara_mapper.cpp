@@ -33,6 +33,7 @@ struct CliOptions
     std::vector<int> devices;           // --devices 0,1,...  (default 0..N-1; a device may be listed twice: two contexts on it, used by the tests)
     std::string shard = "reads";        // --shard reads | bins   (multi_gpu.hpp)
     std::string transport = "auto";     // --transport auto | rccl | copy   (bins mode)
+    int bamLevel = -1;                  // --bam-level 0..9: deflate level of BAM output (default: zlib's, 6)
 };
 
 [[noreturn]] void fail(const std::string & msg) { throw std::runtime_error(msg); }
@@ -85,6 +86,7 @@ CliOptions parse(int argc, char ** argv)
             std::stringstream ss(value()); std::string tok;
             while (std::getline(ss, tok, ',')) { try { o.devices.push_back(std::stoi(tok)); } catch (...) { fail("--devices takes a comma-separated list of device ordinals"); } }
         }
+        else if (a == "--bam-level") o.bamLevel = (int)uintValue(0, 9);
         else if (a == "--shard") { o.shard = value(); if (o.shard != "reads" && o.shard != "bins") fail("--shard takes reads or bins"); }
         else if (a == "--transport") { o.transport = value(); if (o.transport != "auto" && o.transport != "rccl" && o.transport != "copy") fail("--transport takes auto, rccl or copy"); }
         else if (a.size() > 1 && a[0] == '-') fail("unknown option " + a);
@@ -196,7 +198,7 @@ int main(int argc, char ** argv)
             headerText += "@RG\tID:" + opt.readGroup + "\tSM:" + opt.readGroup + "\tPG:Yara\n";
             for (size_t c = 0; c < contigNames.size(); ++c) headerText += "@SQ\tSN:" + contigNames[c] + "\tLN:" + std::to_string(contigLengths[c]) + "\n";
         }
-        BgzfWriter bgzf(os);
+        BgzfWriter bgzf(os, opt.bamLevel);
         const unsigned hostThreads = opt.hostThreads ? opt.hostThreads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         if (bam) bamWriteHeader(bgzf, headerText, contigNames, contigLengths);
         else os << headerText;

@@ -778,6 +778,10 @@ def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
     assert [("@SQ\tSN:%s\tLN:%d" % r) for r in refs] == [l for l in hdr if l.startswith("@SQ")]
     assert recs == [l for l in sam_lines if not l.startswith("@")]
     assert len(recs) == 6400 and n_blocks > 10
+    # --bam-level: the same records whatever the deflate level, a bigger file at level 1
+    bam1 = str(tmp_path / "o1.bam")
+    subprocess.check_call(base + [READS_FA, "-o", bam1, "--bam-level", "1", "-t", "4"])
+    assert bam_to_sam_lines(bam1)[2] == recs and os.path.getsize(bam1) > os.path.getsize(bam)
     assert sam_records(sam_gz) == sam_records(sam)
     assert sam_records(sam) == sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.tag.t1.sam"))
 
