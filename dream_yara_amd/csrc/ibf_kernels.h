@@ -259,6 +259,14 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
 
 // K1 for the headline shape: 64 bins or fewer (W = 1) and 65..127 k-mers per read (reads of 82..144 bases at k = 18).  Same
 // answers as k_ibf_query<7>; the second chunk of k-mers is fetched only as far as the decision needs it.
+// tail k-mers per round: measured on 64 bins / 1 GiB / 100 bp (K1 per 1 M reads): 1 -> 3.81 ms, 2 -> 3.61, 3 -> 3.58, 4 -> 3.57, 5 -> 3.60, 8 -> 3.66, 12 -> 3.76,
+// 19 (the whole tail at once) -> 3.94: the sweep is bound by the look-ups it makes, a round trip more costs less than four look-ups too many
+#ifndef IBF_TAIL_STEP
+#define IBF_TAIL_STEP 4
+#endif
+#ifndef IBF_TAIL_PRE
+#define IBF_TAIL_PRE 4           // tail k-mers requested with the first round
+#endif
 __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ words, IbfGeom g,
                                                        const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
                                                        u32 threshold, u64 * __restrict__ masks, u32 slack)
@@ -290,14 +298,23 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
     // at a time until they are all dead (bound = hits so far + k-mers not yet fetched).
     bool firstIsN[2]; u64 hashA[2], m0[2], hashB[2] = {0, 0}, m1[2] = {0, 0};
     u64 c0p[2][7]; u64 strong[2], weak[2]; u32 fetched[2] = {0, 0}; bool haveHashB[2] = {false, false};
+    // Nearly every strand leaves the first round with a weak bin or two (64 bins: one of them reaches threshold - tail hits by chance), so
+    // the first IBF_TAIL_PRE tail k-mers are requested WITH the first round instead of in a round of their own behind it.
+    const u32 pre = min(tail, (u32)IBF_TAIL_PRE);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
     {
         firstIsN[s] = strandCode(seq, len, 0, s) > 3;
         hashA[s] = laneKmerHash(seq, len, s, 0, lane, k, kMask, firstIsN[s]);
+        if (pre) { hashB[s] = laneKmerHash(seq, len, s, n0, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s) m0[s] = lane < n0 ? words[ibfWordIndex(g, hashA[s], 0)] : 0;
+    for (int s = 0; s < 2; ++s)
+    {
+        m0[s] = lane < n0 ? words[ibfWordIndex(g, hashA[s], 0)] : 0;
+        if (lane < pre) m1[s] = words[ibfWordIndex(g, hashB[s], 0)];
+        fetched[s] = pre;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s)
     {
@@ -305,19 +322,28 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
         const u64 alive0 = planesGe(c0p[s], (int)threshold - (int)tail) & binMask;
         strong[s] = planesGe(c0p[s], (int)threshold) & binMask;
         weak[s] = alive0 & ~strong[s];
+        // what the k-mers fetched ahead already decide
+        u64 todo = pre ? weak[s] : 0;
+        while (todo)
+        {
+            const u32 j = (u32)__ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const u32 c1 = (u32)__popcll(ballot64((m1[s] >> j) & 1));
+            if (planesGet(c0p[s], j) + c1 + (tail - fetched[s]) < threshold) weak[s] &= ~(1ull << j);
+        }
     }
     if (weak[0] | weak[1])
     {
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-            if (weak[s]) { hashB[s] = laneKmerHash(seq, len, s, n0, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
+            if (weak[s] && !haveHashB[s]) { hashB[s] = laneKmerHash(seq, len, s, n0, lane, k, kMask, firstIsN[s]); haveHashB[s] = true; }
         while ((weak[0] && fetched[0] < tail) || (weak[1] && fetched[1] < tail))
         {
 #pragma unroll
             for (int s = 0; s < 2; ++s)
                 if (weak[s] && fetched[s] < tail)
                 {
-                    const u32 upTo = min(tail, fetched[s] + 8);
+                    const u32 upTo = min(tail, fetched[s] + (u32)IBF_TAIL_STEP);
                     if (lane >= fetched[s] && lane < upTo) m1[s] = words[ibfWordIndex(g, hashB[s], 0)];
                     fetched[s] = upTo;
                 }
