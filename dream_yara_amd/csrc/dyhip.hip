@@ -1197,10 +1197,19 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
                 if (W == 1 && nKmax > 64 && nKmax <= 127 && !ctx->tune.ibfFullTail)
                 {
                     const u32 slack = ibfSlack(f, nKmax, threshold);
+                    // tail k-mers requested with the first round: worth their look-ups only where a strand is expected to leave the first
+                    // round with a weak bin (a bin that reaches threshold - tail hits among the first 64 k-mers by chance): 4 at the
+                    // fill of a 1 GiB filter (0.97 weak bins per strand), none at 16 GiB
+                    u32 tailPre = 0;
+                    {
+                        const u32 n0 = std::min<u32>(std::min<u32>(nKmax, 64u), std::max<u32>(threshold, nKmax - std::min<u32>(threshold, nKmax) + slack));
+                        const u32 tail = nKmax - n0;
+                        if (tail && threshold > tail && ibfExpectedFalseCandidates(f, n0, threshold - tail) >= 0.5) tailPre = 4;
+                    }
                     HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
                     ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack;
                     hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>(), slack);
+                                       reads->n, (u32)threshold, reads->masks.as<u64>(), slack, tailPre);
                 }
                 else if (!longReads)
                 {

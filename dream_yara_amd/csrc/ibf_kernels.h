@@ -264,12 +264,11 @@ __global__ __launch_bounds__(256) void k_ibf_query(const u64 * __restrict__ word
 #ifndef IBF_TAIL_STEP
 #define IBF_TAIL_STEP 4
 #endif
-#ifndef IBF_TAIL_PRE
-#define IBF_TAIL_PRE 4           // tail k-mers requested with the first round
-#endif
+// (tailPre, from the host: tail k-mers requested with the first round — 4 where weak bins are the rule, 0 where the filter is so sparse
+// that they are the exception: at 16 GiB / 64 bins the four look-ups per strand cost 3.8 % and save nothing)
 __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ words, IbfGeom g,
                                                        const u8 * __restrict__ seqs, const u64 * __restrict__ offs, u32 nReads,
-                                                       u32 threshold, u64 * __restrict__ masks, u32 slack)
+                                                       u32 threshold, u64 * __restrict__ masks, u32 slack, u32 tailPre)
 {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 read = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -299,8 +298,8 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
     bool firstIsN[2]; u64 hashA[2], m0[2], hashB[2] = {0, 0}, m1[2] = {0, 0};
     u64 c0p[2][7]; u64 strong[2], weak[2]; u32 fetched[2] = {0, 0}; bool haveHashB[2] = {false, false};
     // Nearly every strand leaves the first round with a weak bin or two (64 bins: one of them reaches threshold - tail hits by chance), so
-    // the first IBF_TAIL_PRE tail k-mers are requested WITH the first round instead of in a round of their own behind it.
-    const u32 pre = min(tail, (u32)IBF_TAIL_PRE);
+    // the first tailPre tail k-mers are requested WITH the first round instead of in a round of their own behind it.
+    const u32 pre = min(tail, tailPre);
 #pragma unroll
     for (int s = 0; s < 2; ++s)
     {
