@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_ibf_query_two(const u64 * __restrict__ 
     // The kernel is a chain of dependent gather rounds, so both strands go through every stage together: one round for the first
     // 64 k-mers of both, one per tail group of both, then the verification.
     // After the first 64 k-mers a bin is STRONG (count >= threshold: its verification can succeed on those k-mers alone), WEAK (it
-    // needs tail hits to reach the threshold) or dead.  Weak bins are false candidates almost always; the tail is gathered 8 k-mers
+    // needs tail hits to reach the threshold) or dead.  Weak bins are false candidates almost always; the tail is gathered IBF_TAIL_STEP k-mers
     // at a time until they are all dead (bound = hits so far + k-mers not yet fetched).
     bool firstIsN[2]; u64 hashA[2], m0[2], hashB[2] = {0, 0}, m1[2] = {0, 0};
     u64 c0p[2][7]; u64 strong[2], weak[2]; u32 fetched[2] = {0, 0}; bool haveHashB[2] = {false, false};
