@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--paired", action="store_true", help="paired-end batch: reads/2 pairs of 2 x L bp, insert N(400, 40) (BASELINE configs[3]); not the default metric")
     ap.add_argument("--shard", default="both", choices=["both", "reads", "bins"], help="what is partitioned across ranks (see module docstring); at N = 1 'both' means reads")
     ap.add_argument("--bins-leg-timeout", type=float, default=300.0, help="seconds after which the bins-sharded leg of --shard both is given up (the line is printed without it)")
+    ap.add_argument("--no-prefetch", action="store_true", help="bins-sharded leg: do not queue the next batch's IBF sweep under the current batch's exchanges")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dy_ctx_set_tuning knob for experiments (result-identical code paths; see include/dyhip.h)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
@@ -239,18 +240,21 @@ def main():
         t_load = time.time()
         if mode == "bins":
             from dream_yara_amd import sharded
-            sm = sharded.ShardedMapper(ctx, grp.dist, rank, world, idx_dir, wl["bins"], ibf, "cuda")
+            sm = sharded.ShardedMapper(ctx, grp.dist, rank, world, idx_dir, wl["bins"], ibf, "cuda", prefetch=not args.no_prefetch)
             index = sm.index
         else:
             index = dy.Index(ctx, idx_dir, wl["bins"])
         log("rank %d [%s]: index uploaded in %.1f s" % (rank, mode, time.time() - t_load))
         info = index.info()
 
-        def step(keep_first):
+        def step(keep_first, more_steps=False):
             kept, st_sum, items, raws, st = None, {k: 0.0 for k in STAGES}, 0, 0, None
             for bi, reads in enumerate(batches):
                 if sm is not None:
-                    res = sm.map(reads, params, thr)
+                    # the sweep of the batch mapped next is queued behind this batch's C1 packing (same work inside the timed region:
+                    # the first step sweeps its own batch, the last one queues nothing)
+                    nxt = batches[bi + 1] if bi + 1 < len(batches) else (batches[0] if more_steps else None)
+                    res = sm.map(reads, params, thr, next_reads=nxt)
                 else:
                     # (queuing the NEXT batch's sweep here, on the context's second stream, was measured: +1.5 % — K1 fills every CU and
                     # K2..K4 only run in its tail)
@@ -270,12 +274,13 @@ def main():
 
         for _ in range(args.warmup):
             step(False)
+        ctx.sync()
         stage_ms = {k: 0.0 for k in STAGES}
         barrier(); torch.cuda.synchronize() if torch.cuda.is_available() else None; ctx.sync()
         t_start = time.perf_counter()
         last, items, raws, st = None, 0, 0, None
         for i in range(args.steps):
-            kept, st_sum, items, raws, st = step(i + 1 == args.steps)
+            kept, st_sum, items, raws, st = step(i + 1 == args.steps, more_steps=i + 1 < args.steps)
             for k in STAGES:
                 stage_ms[k] += st_sum[k]
             if kept is not None:

@@ -110,17 +110,17 @@ SYMBOLS = [
     ("dy_kdx_create", C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("dy_kdx_load", C.c_int, [_P, C.c_char_p, C.POINTER(_P)]),
     ("dy_index_load_sharded", C.c_int, [_P, C.c_char_p, C.c_uint32, _P, C.POINTER(_P)]),
-    ("dy_shard_plan", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, _P]),
-    ("dy_shard_pack", C.c_int, [_P, _P, _P, _P, _P, _P]),
-    ("dy_reads_from_device", C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(_P)]),
-    ("dy_reads_from_device_paired", C.c_int, [_P, _P, _P, _P, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.POINTER(_P)]),
-    ("dy_pe_items_pack", C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
+    ("dy_shard_c1_pack", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.POINTER(_P)]),
+    ("dy_shard_c1_unpack", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     ("dy_map_bins", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.POINTER(C.c_uint64)]),
-    ("dy_raw_pack", C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
-    ("dy_finalize_raw", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.c_uint64, _P, C.c_uint64, _P, C.POINTER(_P)]),
+    ("dy_shard_c2_row_bytes", C.c_size_t, [C.c_uint32]),
+    ("dy_shard_c2_pack", C.c_int, [_P, _P, C.POINTER(_P)]),
+    ("dy_shard_finalize", C.c_int, [_P, _P, _P, C.POINTER(Params), _P, C.c_uint32, _P, C.POINTER(_P)]),
 ]
 RAW_MATCH_BYTES = 16
 PE_ITEM_BYTES = 40
+SEG_HEADER_BYTES = 32
+SEG_HEADER_DTYPE = np.dtype([("n_reads", "<u8"), ("n_bases", "<u8"), ("bytes", "<u8"), ("aux", "<u8")])
 
 _lib = None
 
@@ -159,6 +159,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.dy_ctx_sync(self.h))
+
+    def stream(self):
+        """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
+        return self.lib.dy_ctx_stream(self.h) or 0
 
     def set_tuning(self, key, value):
         _check(self.lib.dy_ctx_set_tuning(self.h, key.encode(), int(value)))
@@ -247,18 +251,10 @@ def threshold(error_rate, kmer_size, read_len):
 
 class Reads:
     @classmethod
-    def from_device(cls, ctx, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, paired_seg_starts=None):
-        """A batch from device buffers in dy_shard_pack's layout (raw device addresses).  paired_seg_starts (n_ranks + 1 arrival
-        offsets): a paired job, re-ordered to [first mates | second mates] (dy_reads_from_device_paired)."""
+    def _from_handle(cls, ctx, handle):
         self = cls.__new__(cls)
-        self.ctx, self.lib, self.n = ctx, ctx.lib, n_reads
-        h = _P()
-        if paired_seg_starts is not None:
-            seg = np.ascontiguousarray(paired_seg_starts, dtype=np.uint32)
-            _check(self.lib.dy_reads_from_device_paired(ctx.h, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, seg.size - 1, seg.ctypes.data, C.byref(h)))
-        else:
-            _check(self.lib.dy_reads_from_device(ctx.h, seqs_ptr, lens_ptr, masks_ptr, n_reads, n_bases, n_bins, C.byref(h)))
-        self.h = h
+        self.ctx, self.lib, self.h = ctx, ctx.lib, handle
+        self.n = ctx.lib.dy_reads_count(handle)
         return self
 
     def __init__(self, ctx, codes, offs):
@@ -369,47 +365,51 @@ def map_reads(ctx, index, reads, params, asynchronous=False):
     return Result(ctx, h, reads.n)
 
 
-def shard_plan(ctx, reads, owner_masks, paired=False):
-    """owner_masks: (n_ranks, W) uint64.  Returns (reads per destination rank, bases per destination rank)."""
+def shard_c1_pack(ctx, reads, owner_masks, paired, headers_ptr):
+    """[C1] Queues the packing of the reads selected for every owner rank.  owner_masks: (n_ranks, W) uint64; headers_ptr: device address of
+    n_ranks x SEG_HEADER_BYTES (caller-owned).  Returns the device address of the context's packed send buffer."""
     owner_masks = np.ascontiguousarray(owner_masks, dtype=np.uint64)
-    n_ranks = owner_masks.shape[0]
-    n_to = np.zeros(n_ranks, np.uint32); b_to = np.zeros(n_ranks, np.uint64)
-    _check(ctx.lib.dy_shard_plan(ctx.h, reads.h, n_ranks, owner_masks.ctypes.data, 1 if paired else 0, n_to.ctypes.data, b_to.ctypes.data))
-    return n_to, b_to
+    send = _P()
+    _check(ctx.lib.dy_shard_c1_pack(ctx.h, reads.h, owner_masks.shape[0], owner_masks.ctypes.data, 1 if paired else 0, headers_ptr, C.byref(send)))
+    return send.value or 0
 
 
-def shard_pack(ctx, reads, ids_ptr, lens_ptr, masks_ptr, seqs_ptr):
-    _check(ctx.lib.dy_shard_pack(ctx.h, reads.h, ids_ptr, lens_ptr, masks_ptr, seqs_ptr))
+def shard_c1_unpack(ctx, recv_ptr, recv_headers, n_bins, paired):
+    """The owner-side batch from the received segments.  recv_headers: SEG_HEADER_DTYPE array (host), one row per source rank."""
+    recv_headers = np.ascontiguousarray(recv_headers, dtype=SEG_HEADER_DTYPE)
+    h = _P()
+    _check(ctx.lib.dy_shard_c1_unpack(ctx.h, recv_ptr, recv_headers.size, recv_headers.ctypes.data, n_bins, 1 if paired else 0, C.byref(h)))
+    return Reads._from_handle(ctx, h)
 
 
-def map_bins(ctx, index, reads, params):
-    """K2 + K3 for the resident bins.  Returns (items per bin, number of raw matches left in the context)."""
+def map_bins(ctx, index, reads, params, want_counts=True):
+    """K2 + K3 for the resident bins.  Returns (items per bin, number of raw matches left in the context) or None."""
+    if not want_counts:
+        _check(ctx.lib.dy_map_bins(ctx.h, index.h, reads.h, C.byref(params), None, None))
+        return None
     loads = np.zeros(index.n_bins, np.uint32)
     n_raw = C.c_uint64(0)
     _check(ctx.lib.dy_map_bins(ctx.h, index.h, reads.h, C.byref(params), loads.ctypes.data, C.byref(n_raw)))
     return loads, int(n_raw.value)
 
 
-def raw_pack(ctx, seg_starts, ids_ptr, raw_out_ptr):
-    seg_starts = np.ascontiguousarray(seg_starts, dtype=np.uint32)
-    n_ranks = seg_starts.size - 1
-    n_to = np.zeros(n_ranks, np.uint64)
-    _check(ctx.lib.dy_raw_pack(ctx.h, n_ranks, seg_starts.ctypes.data, ids_ptr, raw_out_ptr, n_to.ctypes.data))
-    return n_to
+def shard_c2_row_bytes(n_bins):
+    return int(load_library().dy_shard_c2_row_bytes(n_bins))
 
 
-def pe_items_pack(ctx, seg_starts, ids_ptr, items_out_ptr):
-    seg_starts = np.ascontiguousarray(seg_starts, dtype=np.uint32)
-    n_ranks = seg_starts.size - 1
-    n_to = np.zeros(n_ranks, np.uint64)
-    _check(ctx.lib.dy_pe_items_pack(ctx.h, n_ranks, seg_starts.ctypes.data, ids_ptr, items_out_ptr, n_to.ctypes.data))
-    return n_to
+def shard_c2_pack(ctx, rows_ptr):
+    """[C2] Queues the packing of the raw matches (+ pairing records) of the last map_bins by home rank; rows_ptr: device address of
+    n_ranks x shard_c2_row_bytes(n_bins).  Returns the device address of the context's packed send buffer."""
+    send = _P()
+    _check(ctx.lib.dy_shard_c2_pack(ctx.h, rows_ptr, C.byref(send)))
+    return send.value or 0
 
 
-def finalize_raw(ctx, index, reads, params, raw_ptr, n_raw, bin_loads, pe_items_ptr=None, n_pe_items=0):
-    bin_loads = np.ascontiguousarray(bin_loads, dtype=np.uint32)
+def shard_finalize(ctx, index, reads, params, recv_ptr, recv_rows, n_ranks):
+    """K4 on the home rank.  recv_rows: uint8 array (host) of n_ranks rows as received."""
+    recv_rows = np.ascontiguousarray(recv_rows, dtype=np.uint8)
     h = _P()
-    _check(ctx.lib.dy_finalize_raw(ctx.h, index.h, reads.h, C.byref(params), raw_ptr, n_raw, pe_items_ptr, n_pe_items, bin_loads.ctypes.data, C.byref(h)))
+    _check(ctx.lib.dy_shard_finalize(ctx.h, index.h, reads.h, C.byref(params), recv_ptr, n_ranks, recv_rows.ctypes.data, C.byref(h)))
     return Result(ctx, h, reads.n)
 
 

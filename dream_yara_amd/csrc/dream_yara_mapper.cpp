@@ -33,6 +33,7 @@ struct CliOptions
     std::vector<int> devices;           // --devices 0,1,...  (default 0..N-1; a device may be listed twice: two contexts on it, used by the tests)
     std::string shard = "reads";        // --shard reads | bins   (multi_gpu.hpp)
     std::string transport = "auto";     // --transport auto | rccl | copy   (bins mode)
+    std::string binAssignment = "lpt";  // --bin-assignment lpt | mod   (bins mode: which device owns which bin)
     int bamLevel = -1;                  // --bam-level 0..9: deflate level of BAM output (default: zlib's, 6)
 };
 
@@ -88,6 +89,7 @@ CliOptions parse(int argc, char ** argv)
         }
         else if (a == "--bam-level") o.bamLevel = (int)uintValue(0, 9);
         else if (a == "--shard") { o.shard = value(); if (o.shard != "reads" && o.shard != "bins") fail("--shard takes reads or bins"); }
+        else if (a == "--bin-assignment") { o.binAssignment = value(); if (o.binAssignment != "lpt" && o.binAssignment != "mod") fail("--bin-assignment takes lpt or mod"); }
         else if (a == "--transport") { o.transport = value(); if (o.transport != "auto" && o.transport != "rccl" && o.transport != "copy") fail("--transport takes auto, rccl or copy"); }
         else if (a.size() > 1 && a[0] == '-') fail("unknown option " + a);
         else pos.push_back(a);
@@ -129,6 +131,20 @@ int main(int argc, char ** argv)
             for (;; ++nBins) { std::ifstream f(opt.indicesDir + std::to_string(nBins) + ".txt.size"); if (!f) break; }
             if (!nBins) fail("Error while opening reference file.");
         }
+        // bin -> device, static per job: longest-processing-time-first on the bins' text sizes (multi_gpu.hpp assignBins; the per-batch
+        // counterpart in the reference is sortedBins(), src/d_mapper.h:843-854), or plain bin mod N (--bin-assignment mod)
+        auto binOwners = [&](uint32_t bins) {
+            std::vector<uint64_t> sizes(bins, 1);
+            if (opt.binAssignment == "lpt")
+                for (uint32_t b = 0; b < bins; ++b)
+                {
+                    std::ifstream f(opt.indicesDir + std::to_string(b) + ".txt.size", std::ios::binary);
+                    uint64_t v[3] = {0, 0, 1};                                     // contigsMaxLength, contigs, contigsSum (reference src/misc_options.h:293-331)
+                    if (f) f.read((char *)v, sizeof v);
+                    sizes[b] = v[2];
+                }
+            return assignBins(sizes, N);
+        };
         {
             std::vector<std::string> errors(N);
             auto setup = [&](unsigned d) {
@@ -146,8 +162,9 @@ int main(int argc, char ** argv)
                     }
                     if (shardBins)
                     {
+                        const std::vector<uint32_t> owner = binOwners(bins);
                         std::vector<uint8_t> owned(bins);
-                        for (uint32_t b = 0; b < bins; ++b) owned[b] = b % N == d;
+                        for (uint32_t b = 0; b < bins; ++b) owned[b] = owner[b] == d;
                         check(dy_index_load_sharded(D.ctx, opt.indicesDir.c_str(), bins, owned.data(), &D.idx));
                     }
                     else check(dy_index_load(D.ctx, opt.indicesDir.c_str(), bins, &D.idx));
@@ -179,7 +196,8 @@ int main(int argc, char ** argv)
                 ShardRank & R = ranks[d];
                 R.rank = d; R.nRanks = N; R.device = devs[d].ordinal; R.ctx = devs[d].ctx; R.ibf = devs[d].ibf; R.idx = devs[d].idx; R.nBins = nBins; R.W = W;
                 R.ownerMasks.assign((size_t)N * W, 0);
-                for (uint32_t b = 0; b < nBins; ++b) R.ownerMasks[(size_t)(b % N) * W + b / 64] |= 1ull << (b % 64);
+                const std::vector<uint32_t> owner = binOwners(nBins);
+                for (uint32_t b = 0; b < nBins; ++b) R.ownerMasks[(size_t)owner[b] * W + b / 64] |= 1ull << (b % 64);
             }
         }
 

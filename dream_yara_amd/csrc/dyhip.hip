@@ -147,17 +147,23 @@ struct dy_ctx
     DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shCnt, shCntOff, shLen, shLenOff, shOwner, shTotals, shSeg, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
+           shLen, shLenOff, shOwner, shTotals, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
     size_t poolCap = 0;
     PinnedBuf hostUp;                   // staging of dy_reads_upload
+    PinnedBuf hostCounters, hostItems;
+    PinnedBuf hostStatus;               // small device -> host fetches (counters, flags): pinned, so that a fetch is one copy + one synchronisation
     PinnedBuf sparePinned[9];           // host arrays of fetched results, handed back by dy_result_free (hipHostMalloc costs milliseconds)
     DevBuf sortKeys;                    // k_finalize_t<BlockGroup>: 128-bit sort keys of reads with more than SORT_CAP matches
     DevBuf packCntSet, packCntOps, packOffSet, packOffOps, packReads, packSet, packOps;     // dy_result_fetch: dense copies made on the device
     DevBuf spare[12];                   // result buffers handed back by dy_result_free (hipMalloc / hipFree cost ~0.1 ms each and hipFree drains the device)
-    // state between dy_shard_plan and dy_shard_pack / dy_map_bins and dy_raw_pack
-    const dy_reads * planReads = nullptr; u32 planRanks = 0; u64 planTotalReads = 0, planTotalBases = 0;
+    // bins sharded over ranks: state between dy_shard_c1_unpack, dy_map_bins and dy_shard_c2_pack (packed exchanges, shard_kernels.h)
+    std::vector<u64> shOwnerHost;       // the ownership table resident in shOwner
+    DevBuf shPairs, shScan, shSegOff, shSend, shIds, shFlags, shFlatLens, shFlatMasks, shCounts, shSegOff2, shSend2, shLoads, shRawFlat;
+    SegTable shArrival = {};            // where each source rank's reads start in the arrival order of the owner-side batch
+    u32 shRanks = 0; const dy_reads * shBatch = nullptr;
     u32 lastRaw = 0; bool rawValid = false;
-    u32 lastItems = 0; bool lastPaired = false; DevBuf shOrig;      // paired dy_map_bins: item count and the batch's arrival indices for dy_raw_pack / dy_pe_items_pack
+    u32 lastItems = 0, lastBins = 0; bool lastPaired = false, lastHasWorkList = false; DevBuf shOrig;      // paired dy_map_bins: the batch's arrival indices for dy_shard_c2_pack
+    const u32 * devItemCount = nullptr; // device copy of the last work list's size
 };
 
 // result buffers are recycled through the context: take the smallest spare that is large enough, else allocate
@@ -374,6 +380,7 @@ static void waitForMasks(dy_ctx * ctx, dy_reads * reads)
 static void collectSweepTime(dy_ctx * ctx, dy_reads * reads)
 {
     if (!reads->k1Pending) return;
+    if (hipEventQuery(reads->evK1[1]) != hipSuccess) return;      // a sweep queued ahead for the NEXT use of these reads (nobody has waited for it yet): leave it alone
     float ms = 0;
     HIP_CHECK(hipEventSynchronize(reads->evK1[1]));
     HIP_CHECK(hipEventElapsedTime(&ms, reads->evK1[0], reads->evK1[1]));
@@ -398,7 +405,9 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
             HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nReads + 1), st));
             ctx->scanTmp.reserve(tmpBytes + 64);
             HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nReads + 1), st));
-            HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nReads, 4, hipMemcpyDeviceToHost, st));
+            ctx->devItemCount = ctx->waveOffsets.as<u32>() + nReads;
+            ctx->hostItems.reserve(64);
+            HIP_CHECK(hipMemcpyAsync(ctx->hostItems.p, ctx->waveOffsets.as<u32>() + nReads, 4, hipMemcpyDeviceToHost, st));
             if ((u64)nReads * nBins > 0x7FFFFFFFull)
             {   // the list is indexed with 31 bits and the 32-bit scan could have wrapped (every read selecting hundreds of bins: an unfiltered
                 // run over many bins): count again in 64 bits
@@ -413,6 +422,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
                 if (exact > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "more than 2^31 (read, bin) pairs in one batch: map fewer reads per batch");
             }
             HIP_CHECK(hipStreamSynchronize(st));
+            nItems = *ctx->hostItems.as<u32>();
             collectSweepTime(ctx, reads);
             ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
             ctx->itemKeys.reserve((size_t)nItems * 4 + 64); ctx->itemPerm.reserve((size_t)nItems * 4 + 64);      // unsorted keys / values (free until the K3 work order)
@@ -446,6 +456,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
         hipLaunchKernelGGL(k_items_bin_starts, dim3((nBins + 1 + 255) / 256), dim3(256), 0, st, ctx->waveOffsets.as<u32>(), ctx->waveOffsets.as<u32>() + nCells,
                            nWaves, nBins, ctx->binStart.as<u32>());
         hipLaunchKernelGGL(k_items_bin_rank, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->binStart.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
+        ctx->devItemCount = ctx->waveOffsets.as<u32>() + nCells;
         HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         collectSweepTime(ctx, reads);
@@ -525,8 +536,10 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
                 else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 HIP_CHECK(hipGetLastError());
             }
-            HIP_CHECK(hipMemcpyAsync(hostCounters, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
+            ctx->hostCounters.reserve(COUNTER_BYTES);
+            HIP_CHECK(hipMemcpyAsync(ctx->hostCounters.p, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
+            memcpy(hostCounters, ctx->hostCounters.p, COUNTER_BYTES);
             memcpy(&poolTotal, hostCounters + COUNTER_POOL64, 8);
             if (!hostCounters[1]) break;
             // every append was counted, stored or not: the count of the failed pass IS the capacity the batch needs (the extension is
@@ -1109,7 +1122,7 @@ int dy_reads_upload(dy_ctx * ctx, const uint8_t * seqs, const uint64_t * offs, u
         }
         else if (total) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs, total, hipMemcpyHostToDevice, ctx->stream));
         HIP_CHECK(hipMemcpyAsync(r->offs.p, offs, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
+        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3(std::min<u32>((n_reads + 15) / 16, 65536u)), dim3(256), 0, ctx->stream, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         *out = r.release();
@@ -1122,6 +1135,7 @@ void dy_reads_free(dy_reads * r)
     if (!r) return;
     (void)hipSetDevice(r->ctx->device);
     if (r->k1Pending) (void)hipEventSynchronize(r->evK1[1]);      // a sweep nobody waited for still writes the masks
+    if (r->ctx->shBatch == r) r->ctx->shBatch = nullptr;
     for (auto & e : r->evK1) if (e) (void)hipEventDestroy(e);
     if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); giveBuffer(r->ctx, r->orig); }
     delete r;
@@ -1620,156 +1634,136 @@ int dy_map_get_stats(const dy_ctx * ctx, dy_map_stats * s)
 }
 
 // ---- bins sharded over ranks --------------------------------------------------------------------------
-int dy_shard_plan(dy_ctx * ctx, const dy_reads * reads, uint32_t n_ranks, const uint64_t * owner_masks, uint32_t paired, uint32_t * n_reads_to, uint64_t * n_bases_to)
+// Per-context state of the packed exchanges (shard_kernels.h): nothing below synchronises with the host — the sizes stay on the device
+// in the header rows until the CALLER fetches them (one stream synchronisation per exchange).
+static SegTable segTableC1(const dy_seg_header * h, u32 nRanks, u32 W, u64 & nReads, u64 & nBases, u32 & maxLen, u32 & minLen)
+{
+    SegTable T; memset(&T, 0, sizeof(T));
+    T.nRanks = nRanks;
+    u64 off = 0; nReads = 0; nBases = 0; maxLen = 0; minLen = 0xFFFFFFFFu;
+    for (u32 s = 0; s < nRanks; ++s)
+    {
+        if (h[s].bytes != c1SegBytes(h[s].n_reads, h[s].n_bases, W)) throw DyError(DY_EINVAL, "dy_shard_c1_unpack: a segment header does not describe its own size");
+        T.off[s] = off; T.start[s] = (u32)nReads;
+        off += h[s].bytes; nReads += h[s].n_reads; nBases += h[s].n_bases;
+        if (nReads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
+        if (h[s].n_reads) { maxLen = std::max(maxLen, (u32)(h[s].aux & 0xFFFFFFFFu)); minLen = std::min(minLen, (u32)(h[s].aux >> 32)); }
+    }
+    T.start[nRanks] = (u32)nReads;
+    if (!nReads) minLen = 0;
+    return T;
+}
+
+int dy_shard_c1_pack(dy_ctx * ctx, dy_reads * reads, uint32_t n_ranks, const uint64_t * owner_masks, uint32_t paired, void * headers_dev, void ** send_dev)
 {
     return guarded([&] {
-        if (!ctx || !reads || !owner_masks || !n_reads_to || !n_bases_to) throw DyError(DY_EINVAL, "dy_shard_plan: NULL argument");
+        if (!ctx || !reads || !owner_masks || !headers_dev || !send_dev) throw DyError(DY_EINVAL, "dy_shard_c1_pack: NULL argument");
         if (reads->ctx != ctx) throw DyError(DY_EINVAL, "reads belong to a different context");
-        if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
+        if (n_ranks == 0 || n_ranks > MAX_RANKS) throw DyError(DY_EINVAL, "1..64 ranks");
         if (!reads->maskW) throw DyError(DY_EINVAL, "dy_ibf_query must run on these reads first");
+        if (paired && (reads->n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
         HIP_CHECK(hipSetDevice(ctx->device));
-        const u32 n = reads->n, W = reads->maskW;
-        const u64 total = (u64)n_ranks * n;
-        if (total + 1 > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "ranks x reads too large for one plan");
-        if (paired && (n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
-        waitForMasks(ctx, const_cast<dy_reads *>(reads));
+        hipStream_t st = ctx->stream;
+        const u32 n = reads->n, W = reads->maskW, nWaves = (n + 63) / 64;
+        waitForMasks(ctx, reads);
         // the four sequences of a pair vote together (reference src/d_mapper.h:350-358): both mates go wherever either is selected
-        if (paired && n) hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(n / 2) * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), n / 2, W);
-        ctx->planReads = nullptr;
-        ctx->shOwner.reserve((size_t)n_ranks * W * 8 + 64);
-        HIP_CHECK(hipMemcpyAsync(ctx->shOwner.p, owner_masks, (size_t)n_ranks * W * 8, hipMemcpyHostToDevice, ctx->stream));
-        ctx->shCnt.reserve((total + 1) * 4); ctx->shCntOff.reserve((total + 1) * 4);
-        ctx->shLen.reserve((total + 1) * 8); ctx->shLenOff.reserve((total + 1) * 8);
-        ctx->shTotals.reserve((size_t)(n_ranks + 1) * 2 * 8 + 64);
-        hipLaunchKernelGGL(k_shard_flags, dim3((u32)((total + 1 + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), reads->offs.as<u64>(), n, W,
-                           ctx->shOwner.as<u64>(), n_ranks, ctx->shCnt.as<u32>(), ctx->shLen.as<u64>());
-        exclusiveSum(ctx, ctx->shCnt.as<u32>(), ctx->shCntOff.as<u32>(), total + 1);
-        exclusiveSum(ctx, ctx->shLen.as<u64>(), ctx->shLenOff.as<u64>(), total + 1);
-        hipLaunchKernelGGL(k_shard_totals, dim3(1), dim3(128), 0, ctx->stream, ctx->shCntOff.as<u32>(), ctx->shLenOff.as<u64>(), n, n_ranks, ctx->shTotals.as<u64>());
-        HIP_CHECK(hipGetLastError());
-        std::vector<u64> tot((size_t)(n_ranks + 1) * 2);
-        HIP_CHECK(hipMemcpyAsync(tot.data(), ctx->shTotals.p, tot.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (u32 d = 0; d < n_ranks; ++d)
+        if (paired && n) hipLaunchKernelGGL(k_pe_or_masks, dim3((u32)(((u64)(n / 2) * W + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), n / 2, W);
+        // ownership is static per job: upload it when it changed
+        const size_t ownerWords = (size_t)n_ranks * W;
+        if (ctx->shOwnerHost.size() != ownerWords || memcmp(ctx->shOwnerHost.data(), owner_masks, ownerWords * 8))
         {
-            n_reads_to[d] = (u32)(tot[d + 1] - tot[d]);
-            n_bases_to[d] = tot[n_ranks + 1 + d + 1] - tot[n_ranks + 1 + d];
+            HIP_CHECK(hipStreamSynchronize(st));                    // an earlier pack may still read the previous table
+            ctx->shOwnerHost.assign(owner_masks, owner_masks + ownerWords);
+            ctx->shOwner.reserve(ownerWords * 8 + 64);
+            HIP_CHECK(hipMemcpy(ctx->shOwner.p, ctx->shOwnerHost.data(), ownerWords * 8, hipMemcpyHostToDevice));
         }
-        collectSweepTime(ctx, const_cast<dy_reads *>(reads));
-        ctx->planReads = reads; ctx->planRanks = n_ranks; ctx->planTotalReads = tot[n_ranks]; ctx->planTotalBases = tot[2 * n_ranks + 1];
+        const size_t nPairs = (size_t)n_ranks * nWaves + 1;
+        ctx->shPairs.reserve(nPairs * sizeof(CountPair) + 64); ctx->shScan.reserve(nPairs * sizeof(CountPair) + 64);
+        ctx->shSegOff.reserve((MAX_RANKS + 1) * 8);
+        hipLaunchKernelGGL(k_c1_count, dim3(std::max(1u, (nWaves + 3) / 4)), dim3(256), 0, st, reads->masks.as<u64>(), reads->offs.as<u64>(), n, W, ctx->shOwner.as<u64>(),
+                           n_ranks, nWaves, ctx->shPairs.as<CountPair>());
+        {
+            size_t tb = 0; CountPair zero; zero.bases = 0; zero.cnt = 0;
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb, ctx->shPairs.as<CountPair>(), ctx->shScan.as<CountPair>(), CountPairSum(), zero, (int)nPairs, st));
+            ctx->scanTmp.reserve(tb + 64);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(ctx->scanTmp.p, tb, ctx->shPairs.as<CountPair>(), ctx->shScan.as<CountPair>(), CountPairSum(), zero, (int)nPairs, st));
+        }
+        const u64 lenRange = (u64)reads->maxLen | ((u64)reads->minLen << 32);
+        hipLaunchKernelGGL(k_c1_headers, dim3(1), dim3(MAX_RANKS), 0, st, ctx->shScan.as<CountPair>(), n_ranks, nWaves, W, lenRange, (SegHeader *)headers_dev, ctx->shSegOff.as<u64>());
+        // room for the worst case (every read selected by every rank): the sizes are not known on the host, and 288 GB make the bound cheap
+        ctx->shSend.reserve((size_t)n_ranks * (c1SegBytes(n, reads->totalBases, W) + 16) + 64);
+        if (nWaves)
+            hipLaunchKernelGGL(k_c1_pack, dim3((nWaves + 3) / 4), dim3(256), 0, st, reads->masks.as<u64>(), reads->offs.as<u64>(), reads->seqs.as<u8>(), n, W, ctx->shOwner.as<u64>(),
+                               n_ranks, nWaves, ctx->shScan.as<CountPair>(), (const SegHeader *)headers_dev, ctx->shSegOff.as<u64>(), ctx->shSend.as<u8>());
+        HIP_CHECK(hipGetLastError());
+        *send_dev = ctx->shSend.p;
     });
 }
 
-int dy_shard_pack(dy_ctx * ctx, const dy_reads * reads, void * ids_dev, void * lens_dev, void * masks_dev, void * seqs_dev)
+int dy_shard_c1_unpack(dy_ctx * ctx, const void * recv_dev, uint32_t n_ranks, const dy_seg_header * recv_headers, uint32_t n_bins, uint32_t paired, dy_reads ** out)
 {
     return guarded([&] {
-        if (!ctx || !reads) throw DyError(DY_EINVAL, "dy_shard_pack: NULL argument");
-        if (ctx->planReads != reads) throw DyError(DY_EINVAL, "dy_shard_plan must run on these reads first");
-        if (ctx->planTotalReads && (!ids_dev || !lens_dev || !masks_dev)) throw DyError(DY_EINVAL, "dy_shard_pack: NULL buffer");
-        if (ctx->planTotalBases && !seqs_dev) throw DyError(DY_EINVAL, "dy_shard_pack: NULL buffer");
-        HIP_CHECK(hipSetDevice(ctx->device));
-        const u32 n = reads->n, W = reads->maskW;
-        const u64 total = (u64)ctx->planRanks * n;
-        if (total)
-            hipLaunchKernelGGL(k_shard_pack, dim3((u32)((total + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), reads->offs.as<u64>(), reads->seqs.as<u8>(),
-                               n, W, ctx->shOwner.as<u64>(), ctx->planRanks, ctx->shCnt.as<u32>(), ctx->shCntOff.as<u32>(), ctx->shLenOff.as<u64>(),
-                               (u32 *)ids_dev, (u32 *)lens_dev, (u64 *)masks_dev, (u8 *)seqs_dev);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-// shared body of dy_reads_from_device / dy_reads_from_device_paired (seg_starts != NULL: paired layout)
-static void readsFromDevice(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
-                            uint32_t n_bins, uint32_t n_ranks, const uint32_t * seg_starts, dy_reads ** out)
-{
-        if (!ctx || !out || (n_reads && (!lens_dev || !masks_dev)) || (n_bases && !seqs_dev)) throw DyError(DY_EINVAL, "dy_reads_from_device: NULL argument");
-        if (n_reads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
+        if (!ctx || !recv_headers || !out) throw DyError(DY_EINVAL, "dy_shard_c1_unpack: NULL argument");
+        if (n_ranks == 0 || n_ranks > MAX_RANKS) throw DyError(DY_EINVAL, "1..64 ranks");
         if (n_bins == 0 || n_bins > 65535) throw DyError(DY_EINVAL, "number of bins out of range");
-        const bool paired = seg_starts != nullptr;
-        if (paired)
-        {
-            if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
-            if (seg_starts[0] != 0 || seg_starts[n_ranks] != n_reads) throw DyError(DY_EINVAL, "seg_starts must run from 0 to n_reads");
-            for (u32 r = 0; r < n_ranks; ++r)
-                if (seg_starts[r + 1] < seg_starts[r] || ((seg_starts[r + 1] - seg_starts[r]) & 1))
-                    throw DyError(DY_EINVAL, "every source segment of a paired batch holds an even number of reads (first mates, then second mates)");
-        }
+        const u32 W = (n_bins + 63) / 64;
+        u64 nReads64 = 0, nBases = 0; u32 maxLen = 0, minLen = 0;
+        const SegTable T = segTableC1(recv_headers, n_ranks, W, nReads64, nBases, maxLen, minLen);
+        const u32 n = (u32)nReads64;
+        if (n && !recv_dev) throw DyError(DY_EINVAL, "dy_shard_c1_unpack: NULL buffer");
+        if (maxLen > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");
+        if (paired) for (u32 s = 0; s < n_ranks; ++s) if (recv_headers[s].n_reads & 1)
+            throw DyError(DY_EINVAL, "every source segment of a paired batch holds an even number of reads (first mates, then second mates)");
         HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
         std::unique_ptr<dy_reads> r(new dy_reads);
-        r->ctx = ctx; r->n = n_reads; r->totalBases = n_bases;
-        r->recycle = true; r->pairLayout = paired;
-        takeBuffer(ctx, r->seqs, n_bases + 64); takeBuffer(ctx, r->seqsRc, n_bases + 64);
-        takeBuffer(ctx, r->offs, (size_t)(n_reads + 1) * 8);
-        const u32 W = (n_bins + 63) / 64;
-        takeBuffer(ctx, r->masks, (size_t)n_reads * W * 8 + 8);
+        r->ctx = ctx; r->n = n; r->totalBases = nBases; r->maxLen = maxLen; r->minLen = minLen;
+        r->recycle = true; r->pairLayout = paired != 0;
+        takeBuffer(ctx, r->seqs, nBases + 64); takeBuffer(ctx, r->seqsRc, nBases + 64);
+        takeBuffer(ctx, r->offs, (size_t)(n + 1) * 8);
+        takeBuffer(ctx, r->masks, (size_t)n * W * 8 + 8);
         r->maskW = W; r->maskBins = n_bins;
-        ctx->shLen.reserve((size_t)(n_reads + 1) * 8);
-        ctx->planReads = nullptr;        // shLen is reused
+        ctx->shIds.reserve((size_t)n * 4 + 64); ctx->shLen.reserve((size_t)(n + 1) * 8);
+        ctx->shFlags.reserve(64);
+        HIP_CHECK(hipMemsetAsync(ctx->shFlags.p, 0, 16, st));
+        const u8 * recv = (const u8 *)recv_dev;
+        const dim3 perRead((n + 1 + 255) / 256), block(256);
         if (!paired)
         {
-            if (n_bases) HIP_CHECK(hipMemcpyAsync(r->seqs.p, seqs_dev, n_bases, hipMemcpyDeviceToDevice, st));
-            if (n_reads) HIP_CHECK(hipMemcpyAsync(r->masks.p, masks_dev, (size_t)n_reads * W * 8, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_widen_lens, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, st, (const u32 *)lens_dev, n_reads, ctx->shLen.as<u64>());
-            exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
+            hipLaunchKernelGGL(k_c1_unpack_scalars, perRead, block, 0, st, recv, T, W, n, ctx->shIds.as<u32>(), ctx->shLen.as<u64>(), r->masks.as<u64>(), ctx->shFlags.as<u32>());
+            exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n + 1);
+            if (n) hipLaunchKernelGGL(k_c1_unpack_bases, dim3(std::min<u32>((n + 15) / 16, 65536u)), block, 0, st, recv, T, W, (const u32 *)nullptr, n, r->offs.as<u64>(), r->offs.as<u64>(),
+                                      nBases, r->seqs.as<u8>(), r->seqsRc.as<u8>(), ctx->shFlags.as<u32>());
         }
         else
         {
-            takeBuffer(ctx, r->orig, (size_t)n_reads * 4 + 64);
-            ctx->shSeg.reserve(64 * 4 * 3 + 64);
-            HIP_CHECK(hipMemcpyAsync(ctx->shSeg.p, seg_starts, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, st));
-            ctx->shLenOff.reserve((size_t)(n_reads + 1) * 8);
-            if (n_reads) hipLaunchKernelGGL(k_pair_layout, dim3((n_reads + 255) / 256), dim3(256), 0, st, ctx->shSeg.as<u32>(), n_ranks, n_reads, r->orig.as<u32>());
-            // offsets of the arrival order (shLenOff) and of the new order (r->offs)
-            hipLaunchKernelGGL(k_widen_lens, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, st, (const u32 *)lens_dev, n_reads, ctx->shLen.as<u64>());
-            exclusiveSum(ctx, ctx->shLen.as<u64>(), ctx->shLenOff.as<u64>(), (size_t)n_reads + 1);
-            hipLaunchKernelGGL(k_permute_scalars, dim3((n_reads + 1 + 255) / 256), dim3(256), 0, st, r->orig.as<u32>(), n_reads, W, (const u32 *)lens_dev, (const u64 *)masks_dev,
-                               ctx->shLen.as<u64>(), r->masks.as<u64>());
-            exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n_reads + 1);
-            if (n_reads) hipLaunchKernelGGL(k_permute_bases, dim3(std::min<u32>((n_reads + 3) / 4, 8192u)), dim3(256), 0, st, r->orig.as<u32>(), n_reads, ctx->shLenOff.as<u64>(),
-                                            (const u8 *)seqs_dev, r->offs.as<u64>(), r->seqs.as<u8>());
+            takeBuffer(ctx, r->orig, (size_t)n * 4 + 64);
+            ctx->shFlatLens.reserve((size_t)(n + 1) * 8); ctx->shFlatMasks.reserve((size_t)n * W * 8 + 64); ctx->shLenOff.reserve((size_t)(n + 1) * 8);
+            if (n) hipLaunchKernelGGL(k_pair_layout, dim3((n + 255) / 256), block, 0, st, T, n, r->orig.as<u32>());
+            hipLaunchKernelGGL(k_c1_unpack_scalars, perRead, block, 0, st, recv, T, W, n, ctx->shIds.as<u32>(), ctx->shFlatLens.as<u64>(), ctx->shFlatMasks.as<u64>(), ctx->shFlags.as<u32>());
+            exclusiveSum(ctx, ctx->shFlatLens.as<u64>(), ctx->shLenOff.as<u64>(), (size_t)n + 1);                // offsets in arrival order
+            hipLaunchKernelGGL(k_permute_scalars, perRead, block, 0, st, r->orig.as<u32>(), n, W, ctx->shFlatLens.as<u64>(), ctx->shFlatMasks.as<u64>(), ctx->shLen.as<u64>(), r->masks.as<u64>());
+            exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n + 1);                           // offsets of the re-ordered batch
+            if (n) hipLaunchKernelGGL(k_c1_unpack_bases, dim3(std::min<u32>((n + 15) / 16, 65536u)), block, 0, st, recv, T, W, r->orig.as<u32>(), n, ctx->shLenOff.as<u64>(), r->offs.as<u64>(),
+                                      nBases, r->seqs.as<u8>(), r->seqsRc.as<u8>(), ctx->shFlags.as<u32>());
         }
-        if (n_reads) hipLaunchKernelGGL(k_revcomp_reads, dim3((n_reads + 255) / 256), dim3(256), 0, st, r->seqs.as<u8>(), r->seqsRc.as<u8>(), r->offs.as<u64>(), n_reads);
         HIP_CHECK(hipGetLastError());
-        // length statistics on the device (the lengths themselves stay there: a batch built this way is searched, never reported)
-        unsigned long long hostStats[3] = {0, 0, ~0ull};
-        ctx->shTotals.reserve(64);
-        HIP_CHECK(hipMemcpyAsync(ctx->shTotals.p, hostStats, 24, hipMemcpyHostToDevice, st));
-        if (n_reads) hipLaunchKernelGGL(k_lens_stats, dim3(256), dim3(256), 0, st, (const u32 *)lens_dev, n_reads, ctx->shTotals.as<unsigned long long>());
-        HIP_CHECK(hipMemcpyAsync(hostStats, ctx->shTotals.p, 24, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        const u64 sum = hostStats[0]; const u32 mx = (u32)hostStats[1], mn = (u32)hostStats[2];
-        if (mx > 8191) throw DyError(DY_EINVAL, "Maximum read length exceeded.");
-        if (sum != n_bases) throw DyError(DY_EINVAL, "dy_reads_from_device: lengths do not add up to n_bases");
-        r->maxLen = mx; r->minLen = n_reads ? mn : 0;
+        // what dy_shard_c2_pack needs of this batch: where each source's reads start in arrival order
+        ctx->shArrival = T;
+        ctx->shRanks = n_ranks; ctx->shBatch = r.get(); ctx->rawValid = false;
         *out = r.release();
-}
-
-int dy_reads_from_device(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
-                         uint32_t n_bins, dy_reads ** out)
-{
-    return guarded([&] { readsFromDevice(ctx, seqs_dev, lens_dev, masks_dev, n_reads, n_bases, n_bins, 0, nullptr, out); });
-}
-
-int dy_reads_from_device_paired(dy_ctx * ctx, const void * seqs_dev, const void * lens_dev, const void * masks_dev, uint32_t n_reads, uint64_t n_bases,
-                                uint32_t n_bins, uint32_t n_ranks, const uint32_t * seg_starts, dy_reads ** out)
-{
-    return guarded([&] {
-        if (!seg_starts) throw DyError(DY_EINVAL, "dy_reads_from_device_paired: seg_starts is NULL");
-        readsFromDevice(ctx, seqs_dev, lens_dev, masks_dev, n_reads, n_bases, n_bins, n_ranks, seg_starts, out);
     });
 }
 
 int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, uint32_t * bin_loads, uint64_t * n_raw)
 {
     return guarded([&] {
-        if (!ctx || !idx || !reads || !p || !bin_loads || !n_raw) throw DyError(DY_EINVAL, "dy_map_bins: NULL argument");
+        if (!ctx || !idx || !reads || !p) throw DyError(DY_EINVAL, "dy_map_bins: NULL argument");
         if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
         if (p->sensitivity > 2) throw DyError(DY_EINVAL, "sensitivity must be 0 (low), 1 (high) or 2 (full)");
         if (!(p->error_rate >= 0.0f && p->error_rate <= 0.10f)) throw DyError(DY_EINVAL, "error rate must be within [0, 0.10]");
         const bool paired = p->paired != 0;
-        if (paired && !reads->pairLayout) throw DyError(DY_EINVAL, "a paired dy_map_bins needs a batch built by dy_reads_from_device_paired");
+        if (paired && !reads->pairLayout) throw DyError(DY_EINVAL, "a paired dy_map_bins needs a batch built by dy_shard_c1_unpack");
         HIP_CHECK(hipSetDevice(ctx->device));
         const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
         if (reads->maskW != W || reads->maskBins != nBins) throw DyError(DY_EINVAL, "the reads carry no bin masks for this index");
@@ -1777,9 +1771,10 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
         const u32 S0 = seedCountOf(maxErr, 0);
         if (S0 > MAX_SEEDS) throw DyError(DY_EUNSUPPORTED, "more than 32 seeds per read (read length x error rate too large)");
         ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
-        ctx->rawValid = false; ctx->lastRaw = 0; ctx->lastItems = 0; ctx->lastPaired = paired;
-        for (u32 b = 0; b < nBins; ++b) bin_loads[b] = 0;
-        *n_raw = 0;
+        ctx->rawValid = false; ctx->lastRaw = 0; ctx->lastItems = 0; ctx->lastPaired = paired; ctx->lastBins = nBins; ctx->lastHasWorkList = false;
+        if (ctx->shBatch != reads) ctx->shRanks = 0;            // not a batch of dy_shard_c1_unpack: dy_shard_c2_pack has no arrival table for it
+        if (bin_loads) for (u32 b = 0; b < nBins; ++b) bin_loads[b] = 0;
+        if (n_raw) *n_raw = 0;
         if (!nReads) { ctx->rawValid = true; return; }
         // never search a bin whose FM structures are not resident
         hipLaunchKernelGGL(k_and_masks, dim3((u32)(((u64)nReads * W + 255) / 256)), dim3(256), 0, ctx->stream, reads->masks.as<u64>(), nReads, W, idx->dOwnedMask.as<u64>());
@@ -1791,15 +1786,19 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
             ctx->shOrig.reserve((size_t)nReads * 4 + 64);
             HIP_CHECK(hipMemcpyAsync(ctx->shOrig.p, reads->orig.p, (size_t)nReads * 4, hipMemcpyDeviceToDevice, ctx->stream));
         }
-        std::vector<u32> starts(nBins + 1);
-        HIP_CHECK(hipMemcpyAsync(starts.data(), ctx->binStart.p, (size_t)(nBins + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        u32 badGroup = 0;
-        HIP_CHECK(hipMemcpyAsync(&badGroup, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (badGroup) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
-        for (u32 b = 0; b < nBins; ++b) bin_loads[b] = starts[b + 1] - starts[b];
-        *n_raw = nPool;
-        ctx->lastRaw = nPool; ctx->lastItems = nItems; ctx->rawValid = true;
+        // one pinned fetch (every pageable copy is a round trip of its own): the flags, and the work list's bin boundaries if asked for
+        ctx->hostStatus.reserve((size_t)(nBins + 1) * 4 + 64);
+        u32 * status = ctx->hostStatus.as<u32>();
+        status[0] = status[1] = 0;
+        if (paired) HIP_CHECK(hipMemcpyAsync(status, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, ctx->stream));      // k_group_matches ran (pairing stages)
+        if (ctx->shBatch == reads) HIP_CHECK(hipMemcpyAsync(status + 1, ctx->shFlags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (bin_loads) HIP_CHECK(hipMemcpyAsync(status + 16, ctx->binStart.p, (size_t)(nBins + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (paired || ctx->shBatch == reads || bin_loads) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (status[1]) throw DyError(DY_EINVAL, "dy_shard_c1_unpack: the received segments are inconsistent with their headers");
+        if (status[0]) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
+        if (bin_loads) for (u32 b = 0; b < nBins; ++b) bin_loads[b] = status[16 + b + 1] - status[16 + b];
+        if (n_raw) *n_raw = nPool;
+        ctx->lastRaw = nPool; ctx->lastItems = nItems; ctx->rawValid = true; ctx->lastHasWorkList = true;
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;
@@ -1807,92 +1806,79 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
     });
 }
 
-// shared by dy_raw_pack / dy_pe_items_pack: per-source counts -> host, cursors -> device
-static void segCursors(dy_ctx * ctx, u32 n_ranks, const u32 * seg_starts, u32 *& segDev, u32 *& counts, u32 *& cursors)
-{
-    ctx->shSeg.reserve(64 * 4 * 3 + 64);
-    segDev = ctx->shSeg.as<u32>(); counts = segDev + 80; cursors = segDev + 160;
-    HIP_CHECK(hipMemcpyAsync(segDev, seg_starts, (size_t)(n_ranks + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipMemsetAsync(counts, 0, 64 * 4, ctx->stream));
-}
-static u32 segCountsToCursors(dy_ctx * ctx, u32 n_ranks, u32 * counts, u32 * cursors, uint64_t * n_to)
-{
-    u32 hostCounts[64];
-    HIP_CHECK(hipMemcpyAsync(hostCounts, counts, (size_t)n_ranks * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    u32 hostCursor[64]; u32 acc = 0;
-    for (u32 s = 0; s < n_ranks; ++s) { hostCursor[s] = acc; acc += hostCounts[s]; n_to[s] = hostCounts[s]; }
-    HIP_CHECK(hipMemcpyAsync(cursors, hostCursor, (size_t)n_ranks * 4, hipMemcpyHostToDevice, ctx->stream));
-    return acc;
-}
+size_t dy_shard_c2_row_bytes(uint32_t n_bins) { return sizeof(SegHeader) + (((size_t)n_bins * 4 + 7) & ~(size_t)7); }
 
-int dy_raw_pack(dy_ctx * ctx, uint32_t n_ranks, const uint32_t * seg_starts, const void * ids_dev, void * raw_out_dev, uint64_t * n_raw_to)
+int dy_shard_c2_pack(dy_ctx * ctx, void * rows_dev, void ** send_dev)
 {
     return guarded([&] {
-        if (!ctx || !seg_starts || !n_raw_to) throw DyError(DY_EINVAL, "dy_raw_pack: NULL argument");
-        if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
-        if (!ctx->rawValid) throw DyError(DY_EINVAL, "dy_map_bins must run first");
-        for (u32 s = 0; s < n_ranks; ++s) if (seg_starts[s + 1] < seg_starts[s]) throw DyError(DY_EINVAL, "seg_starts must be non-decreasing");
-        HIP_CHECK(hipSetDevice(ctx->device));
-        const u32 n = ctx->lastRaw;
-        for (u32 s = 0; s < n_ranks; ++s) n_raw_to[s] = 0;
-        if (!n) return;
-        if (!ids_dev || !raw_out_dev) throw DyError(DY_EINVAL, "dy_raw_pack: NULL buffer");
-        u32 * segDev, * counts, * cursors;
-        segCursors(ctx, n_ranks, seg_starts, segDev, counts, cursors);
-        const u32 * orig = ctx->lastPaired ? ctx->shOrig.as<u32>() : nullptr;
-        hipLaunchKernelGGL(k_raw_seg_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, orig, counts);
-        if (segCountsToCursors(ctx, n_ranks, counts, cursors, n_raw_to) != n) throw DyError(DY_EINVAL, "dy_raw_pack: seg_starts do not cover the reads of the last dy_map_bins");
-        hipLaunchKernelGGL(k_raw_seg_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->pool.as<RawMatch>(), n, segDev, n_ranks, orig, (const u32 *)ids_dev, cursors,
-                           (RawMatch *)raw_out_dev);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int dy_pe_items_pack(dy_ctx * ctx, uint32_t n_ranks, const uint32_t * seg_starts, const void * ids_dev, void * items_out_dev, uint64_t * n_items_to)
-{
-    return guarded([&] {
-        if (!ctx || !seg_starts || !n_items_to) throw DyError(DY_EINVAL, "dy_pe_items_pack: NULL argument");
-        if (n_ranks == 0 || n_ranks > 64) throw DyError(DY_EINVAL, "1..64 ranks");
-        if (!ctx->rawValid || !ctx->lastPaired) throw DyError(DY_EINVAL, "a paired dy_map_bins must run first");
-        for (u32 s = 0; s < n_ranks; ++s) if (seg_starts[s + 1] < seg_starts[s]) throw DyError(DY_EINVAL, "seg_starts must be non-decreasing");
-        HIP_CHECK(hipSetDevice(ctx->device));
-        const u32 n = ctx->lastItems;
-        for (u32 s = 0; s < n_ranks; ++s) n_items_to[s] = 0;
-        if (!n) return;
-        if (!ids_dev || !items_out_dev) throw DyError(DY_EINVAL, "dy_pe_items_pack: NULL buffer");
-        u32 * segDev, * counts, * cursors;
-        segCursors(ctx, n_ranks, seg_starts, segDev, counts, cursors);
-        hipLaunchKernelGGL(k_pe_items_seg_count, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), n, segDev, n_ranks,
-                           ctx->shOrig.as<u32>(), counts);
-        (void)segCountsToCursors(ctx, n_ranks, counts, cursors, n_items_to);
-        hipLaunchKernelGGL(k_pe_items_seg_scatter, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(), n,
-                           segDev, n_ranks, ctx->shOrig.as<u32>(), (const u32 *)ids_dev, cursors, (PeItemRec *)items_out_dev);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    });
-}
-
-int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, const void * raw_dev, uint64_t n_raw,
-                    const void * pe_items_dev, uint64_t n_pe_items, const uint32_t * bin_loads, dy_result ** out)
-{
-    return guarded([&] {
-        if (!ctx || !idx || !reads || !p || !bin_loads || !out || (n_raw && !raw_dev) || (n_pe_items && !pe_items_dev)) throw DyError(DY_EINVAL, "dy_finalize_raw: NULL argument");
-        if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
-        if (n_raw >= 0xFFFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
-        const bool paired = p->paired != 0;
-        if (!paired && n_pe_items) throw DyError(DY_EINVAL, "dy_finalize_raw: paired-end item records given for a single-end batch");
-        if (paired && (reads->n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
-        if (n_pe_items >= 0xFFFFFFF0ull) throw DyError(DY_EINVAL, "dy_finalize_raw: too many item records");
+        if (!ctx || !rows_dev || !send_dev) throw DyError(DY_EINVAL, "dy_shard_c2_pack: NULL argument");
+        if (!ctx->rawValid || !ctx->shRanks) throw DyError(DY_EINVAL, "dy_map_bins on a batch of dy_shard_c1_unpack must run first");
         HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
-        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), nPool = (u32)n_raw, W = (nBins + 63) / 64;
-        if (paired && (reads->maskW != W || reads->maskBins != nBins)) throw DyError(DY_EINVAL, "the reads carry no bin masks for this index (dy_ibf_query + dy_shard_plan first)");
+        const u32 nRanks = ctx->shRanks, n = ctx->lastRaw, nItems = ctx->lastItems, nBins = ctx->lastBins;
+        const bool paired = ctx->lastPaired;
+        const SegTable & T = ctx->shArrival;
+        ctx->shCounts.reserve(4 * MAX_RANKS * 4 + 64);
+        u32 * counts = ctx->shCounts.as<u32>(), * itemCounts = counts + MAX_RANKS, * cursors = counts + 2 * MAX_RANKS;     // cursors: raw, then pairing records
+        HIP_CHECK(hipMemsetAsync(counts, 0, 2 * MAX_RANKS * 4, st));
+        const u32 * orig = paired ? ctx->shOrig.as<u32>() : nullptr;
+        const u32 * nPoolDev = ctx->counters.as<u32>() + COUNTER_POOL64, * nItemsDev = ctx->devItemCount;
+        const u32 rawBlocks = std::min<u32>((n + 255) / 256, 2048u), itemBlocks = std::min<u32>((nItems + 255) / 256, 2048u);
+        if (n) hipLaunchKernelGGL(k_raw_seg_count, dim3(rawBlocks), dim3(256), 0, st, ctx->pool.as<RawMatch>(), nPoolDev, T, orig, counts);
+        if (paired && nItems)
+            hipLaunchKernelGGL(k_pe_items_seg_count, dim3(itemBlocks), dim3(256), 0, st, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), nItemsDev, T, orig, itemCounts);
+        ctx->shSegOff2.reserve((MAX_RANKS + 1) * 8);
+        hipLaunchKernelGGL(k_c2_rows, dim3(nRanks), dim3(256), 0, st, counts, paired ? itemCounts : (const u32 *)nullptr, nRanks, ctx->lastHasWorkList ? ctx->binStart.as<u32>() : (const u32 *)nullptr,
+                           nBins, (u32)dy_shard_c2_row_bytes(nBins), (u8 *)rows_dev, ctx->shSegOff2.as<u64>(), cursors);
+        ctx->shSend2.reserve((size_t)n * sizeof(RawMatch) + (paired ? (size_t)nItems * sizeof(PeItemRec) : 0) + (size_t)nRanks * 16 + 64);
+        if (n) hipLaunchKernelGGL(k_raw_seg_scatter, dim3(rawBlocks), dim3(256), 0, st, ctx->pool.as<RawMatch>(), nPoolDev, T, orig, ctx->shIds.as<u32>(), cursors,
+                                  ctx->shSegOff2.as<u64>(), ctx->shSend2.as<u8>());
+        if (paired && nItems)
+            hipLaunchKernelGGL(k_pe_items_seg_scatter, dim3(itemBlocks), dim3(256), 0, st, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(), nItemsDev, T, orig,
+                               ctx->shIds.as<u32>(), cursors + MAX_RANKS, ctx->shSegOff2.as<u64>(), counts, ctx->shSend2.as<u8>());
+        HIP_CHECK(hipGetLastError());
+        *send_dev = ctx->shSend2.p;
+    });
+}
+
+int dy_shard_finalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, const void * recv_dev, uint32_t n_ranks, const void * recv_rows,
+                      dy_result ** out)
+{
+    return guarded([&] {
+        if (!ctx || !idx || !reads || !p || !recv_rows || !out) throw DyError(DY_EINVAL, "dy_shard_finalize: NULL argument");
+        if (idx->ctx != ctx || reads->ctx != ctx) throw DyError(DY_EINVAL, "index/reads belong to a different context");
+        if (n_ranks == 0 || n_ranks > MAX_RANKS) throw DyError(DY_EINVAL, "1..64 ranks");
+        const bool paired = p->paired != 0;
+        if (paired && (reads->n & 1)) throw DyError(DY_EINVAL, "a paired batch holds an even number of reads (first mates, then second mates)");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
+        if (paired && (reads->maskW != W || reads->maskBins != nBins)) throw DyError(DY_EINVAL, "the reads carry no bin masks for this index (dy_ibf_query + dy_shard_c1_pack first)");
+        // the rows of all sources: segment sizes, and the items per bin of the whole job (sortedBins(), reference src/d_mapper.h:843-854)
+        const size_t rowBytes = dy_shard_c2_row_bytes(nBins);
+        SegTable T; memset(&T, 0, sizeof(T)); T.nRanks = n_ranks;
+        std::vector<u32> loads(nBins, 0);
+        u64 off = 0, nRaw = 0, nPeItems = 0;
+        for (u32 s = 0; s < n_ranks; ++s)
+        {
+            SegHeader h; memcpy(&h, (const u8 *)recv_rows + s * rowBytes, sizeof(h));
+            if (h.bytes != c2SegBytes(h.a, h.b)) throw DyError(DY_EINVAL, "dy_shard_finalize: a segment header does not describe its own size");
+            T.off[s] = off; T.start[s] = (u32)nRaw; T.start2[s] = (u32)nPeItems;
+            off += h.bytes; nRaw += h.a; nPeItems += h.b;
+            if (nRaw >= 0xFFFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+            if (nPeItems >= 0xFFFFFFF0ull) throw DyError(DY_EINVAL, "dy_shard_finalize: too many pairing records");
+            const u32 * l = (const u32 *)((const u8 *)recv_rows + s * rowBytes + sizeof(SegHeader));
+            for (u32 b = 0; b < nBins; ++b) loads[b] = (u32)std::min<u64>((u64)loads[b] + l[b], 0xFFFFFFFFull);
+        }
+        T.start[n_ranks] = (u32)nRaw; T.start2[n_ranks] = (u32)nPeItems;
+        if (!paired && nPeItems) throw DyError(DY_EINVAL, "dy_shard_finalize: pairing records given for a single-end batch");
+        if ((nRaw || nPeItems) && !recv_dev) throw DyError(DY_EINVAL, "dy_shard_finalize: NULL buffer");
+        const u32 nPool = (u32)nRaw;
         const u32 maxErr = readErrorsOf(reads->maxLen, p->error_rate);
         const u32 maxMatchErr = maxMatchErrorsOf(reads, p, maxErr);
         std::unique_ptr<dy_result> res = makeResult(ctx, reads, maxMatchErr);
         res->nPool = nPool;
+        ctx->stats.raw_matches = nPool;
         if (!nReads) { *out = res.release(); return; }
         ctx->counters.reserve(COUNTER_BYTES);
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
@@ -1900,6 +1886,7 @@ int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const 
         HIP_CHECK(hipMemsetAsync(ctx->readMatchCount.p, 0, (size_t)(nReads + 1) * 4, st));
         HIP_CHECK(hipEventRecord(ctx->ev[5], st));
         u32 nItems = 0;
+        const u8 * recv = (const u8 *)recv_dev;
         if (paired)
         {   // the home reads' own work list (their OR-ed masks) indexes the records of the owners: copyCigars, reference src/d_mapper.h:186-215
             nItems = buildWorkList(ctx, reads, nBins);
@@ -1907,42 +1894,33 @@ int dy_finalize_raw(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const 
             ctx->peHasRescue.reserve((size_t)nReads * 4 + 64);
             HIP_CHECK(hipMemsetAsync(ctx->peItems.p, 0, (size_t)nItems * sizeof(PeItem), st));
             HIP_CHECK(hipMemsetAsync(ctx->peHasRescue.p, 0, (size_t)nReads * 4, st));
-            if (n_pe_items)
+            if (nPeItems)
             {
                 PeView V = {};
                 V.items = ctx->peItems.as<PeItem>(); V.itemRead = ctx->itemRead.as<u32>(); V.itemBin = ctx->itemBin.as<u16>(); V.binStart = ctx->binStart.as<u32>();
                 V.nBins = nBins; V.nItems = nItems; V.readHasRescue = ctx->peHasRescue.as<u32>();
-                hipLaunchKernelGGL(k_pe_items_unpack, dim3((u32)((n_pe_items + 255) / 256)), dim3(256), 0, st, (const PeItemRec *)pe_items_dev, (u32)n_pe_items, V, nReads,
-                                   ctx->counters.as<u32>() + 7);
+                hipLaunchKernelGGL(k_pe_items_unpack, dim3((u32)((nPeItems + 255) / 256)), dim3(256), 0, st, recv, T, (u32)nPeItems, V, nReads, ctx->counters.as<u32>() + 7);
             }
         }
-        // sortedBins() over the loads of the whole job (reference src/d_mapper.h:843-854), as k_items_bin_starts ranks them
-        std::vector<u32> rank(nBins);
-        for (u32 b = 0; b < nBins; ++b)
-        {
-            u32 r = 0;
-            for (u32 o = 0; o < nBins; ++o) if (bin_loads[o] > bin_loads[b] || (bin_loads[o] == bin_loads[b] && o < b)) ++r;
-            rank[b] = r;
-        }
-        ctx->binOrderRank.reserve((size_t)nBins * 4);
-        HIP_CHECK(hipMemcpyAsync(ctx->binOrderRank.p, rank.data(), (size_t)nBins * 4, hipMemcpyHostToDevice, st));
+        // sortedBins() over the loads of the whole job
+        ctx->binOrderRank.reserve((size_t)nBins * 4); ctx->shLoads.reserve((size_t)nBins * 4 + 64);
+        HIP_CHECK(hipMemcpyAsync(ctx->shLoads.p, loads.data(), (size_t)nBins * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_bin_rank_from_loads, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->shLoads.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
+        ctx->shRawFlat.reserve((size_t)nPool * sizeof(RawMatch) + 64);
         if (nPool)
-            hipLaunchKernelGGL(k_raw_read_counts, dim3((nPool + 255) / 256), dim3(256), 0, st, (const RawMatch *)raw_dev, nPool, nReads, ctx->readMatchCount.as<u32>(),
+            hipLaunchKernelGGL(k_c2_unpack_raw, dim3((nPool + 255) / 256), dim3(256), 0, st, recv, T, nPool, nReads, ctx->shRawFlat.as<RawMatch>(), ctx->readMatchCount.as<u32>(),
                                ctx->counters.as<u32>() + 7);
-        u32 bad = 0;
-        HIP_CHECK(hipMemcpyAsync(&bad, ctx->counters.as<u32>() + 7, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (bad) throw DyError(DY_EINVAL, "dy_finalize_raw: a raw match or item record names a read / bin outside the batch's selection");
-        runFinalize(ctx, idx, reads, p, res.get(), (const RawMatch *)raw_dev, nPool, nItems, maxMatchErr, PE_HOME);
+        runFinalize(ctx, idx, reads, p, res.get(), ctx->shRawFlat.as<RawMatch>(), nPool, nItems, maxMatchErr, PE_HOME);
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
         res->readLens = reads->lens;
-        u32 badGroup = 0;
-        HIP_CHECK(hipMemcpyAsync(&badGroup, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, st));
+        u32 flags[COUNTER_BYTES / 4];
+        HIP_CHECK(hipMemcpyAsync(flags, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        if (badGroup) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
+        collectSweepTime(ctx, reads);
+        if (flags[7]) throw DyError(DY_EINVAL, "dy_shard_finalize: a raw match or pairing record names a read / bin outside the batch's selection");
+        if (flags[COUNTER_BAD_GROUP]) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->stats.ms_finalize = ms;
-        ctx->stats.raw_matches = nPool;
         *out = res.release();
     });
 }

@@ -24,22 +24,43 @@ struct ReadsView
     u32         nReads;
 };
 
-// one thread per read writes its reverse complement, 8 bases per step (byte swap; A<->T, C<->G is code ^ 3, N = 4 stays)
+// ---- byte strings moved by groups of 16 lanes, 8 bytes per lane and step (unaligned 8-byte accesses): a 100-base read is one step.
+// A thread per read (or a wavefront per read, a byte per lane) spends 4-10x the memory instructions on the same bytes.
 struct __attribute__((packed)) PackedU64rc { u64 v; };
-__global__ void k_revcomp_reads(const u8 * __restrict__ fwd, u8 * __restrict__ rc, const u64 * __restrict__ offs, u32 nReads)
+__device__ __forceinline__ u64 revcomp8(u64 w)          // the 8 Dna5 codes of w reversed and complemented (A<->T, C<->G is code ^ 3, N = 4 stays)
 {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nReads) return;
-    const u64 o = offs[r];
-    const u32 len = (u32)(offs[r + 1] - o);
-    u32 i = 0;
-    for (; i + 8 <= len; i += 8)
+    const u64 r = __builtin_bswap64(w);
+    const u64 isN = ((r >> 2) & 0x0101010101010101ull) * 0xFFull;
+    return r ^ (0x0303030303030303ull & ~isN);
+}
+// g = lane of the group (0..15).  Copies src[0, len) to dst; rc (may be NULL) receives the reverse complement.
+__device__ __forceinline__ void groupCopyRead(const u8 * __restrict__ src, u8 * __restrict__ dst, u8 * __restrict__ rc, u32 len, u32 g)
+{
+    for (u32 p = g * 8; p + 8 <= len; p += 128)
     {
-        const u64 w = __builtin_bswap64(((const PackedU64rc *)(fwd + o + len - 8 - i))->v);
-        const u64 isN = ((w >> 2) & 0x0101010101010101ull) * 0xFFull;
-        ((PackedU64rc *)(rc + o + i))->v = w ^ (0x0303030303030303ull & ~isN);
+        const u64 w = ((const PackedU64rc *)(src + p))->v;
+        if (dst) ((PackedU64rc *)(dst + p))->v = w;
+        if (rc) ((PackedU64rc *)(rc + len - 8 - p))->v = revcomp8(w);
     }
-    for (; i < len; ++i) { const u8 c = fwd[o + len - 1 - i]; rc[o + i] = c < 4 ? (u8)(3 - c) : c; }
+    const u32 t = len & ~7u;
+    if (g < (len & 7u))
+    {
+        const u8 c = src[t + g];
+        if (dst) dst[t + g] = c;
+        if (rc) rc[len - 1 - (t + g)] = c < 4 ? (u8)(3 - c) : c;
+    }
+}
+
+// reverse complements of a batch (appendReverseComplement, reference src/store_seqs.h:271-290): 16 lanes per read
+__global__ __launch_bounds__(256) void k_revcomp_reads(const u8 * __restrict__ fwd, u8 * __restrict__ rc, const u64 * __restrict__ offs, u32 nReads)
+{
+    const u32 g = threadIdx.x & 15;
+    const u32 group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, nGroups = (gridDim.x * blockDim.x) >> 4;
+    for (u32 r = group; r < nReads; r += nGroups)
+    {
+        const u64 o = offs[r];
+        groupCopyRead(fwd + o, nullptr, rc + o, (u32)(offs[r + 1] - o), g);
+    }
 }
 
 // ---- 8-bytes-at-a-time comparison of Dna5 code strings (N = 4 never matches, reference src/basic_alphabet.h:47) ----

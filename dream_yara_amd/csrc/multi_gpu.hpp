@@ -12,7 +12,11 @@
 #include "../../include/dyhip.h"
 #include <hip/hip_runtime_api.h>
 #include <dlfcn.h>
+#include <algorithm>
 #include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <unistd.h>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -83,12 +87,34 @@ struct RcclApi
     void check(int rc, const char * what) const { if (rc != 0) throw GpuError(std::string(what) + ": " + (GetErrorString ? GetErrorString(rc) : "RCCL error")); }
 };
 
-// all-to-all(v) of bytes between the N rank threads of this process
+// Bin -> rank assignment, static per job (the FM structures stay resident): longest-processing-time-first on the bins' text sizes
+// (<dir>/<b>.txt.size: contigsSum), the static counterpart of sortedBins() (reference src/d_mapper.h:843-854), which orders the bins of
+// every batch by their read counts: the largest bin goes to the least loaded rank (ties: lowest rank), so equal bins fall out as
+// bin mod N.  sizes empty or all equal -> bin mod N.
+inline std::vector<uint32_t> assignBins(const std::vector<uint64_t> & sizes, unsigned nRanks)
+{
+    const uint32_t nBins = (uint32_t)sizes.size();
+    std::vector<uint32_t> order(nBins), owner(nBins, 0);
+    for (uint32_t b = 0; b < nBins; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return sizes[x] > sizes[y]; });
+    std::vector<uint64_t> load(nRanks, 0);
+    for (uint32_t b : order)
+    {
+        unsigned best = 0;
+        for (unsigned r = 1; r < nRanks; ++r) if (load[r] < load[best]) best = r;
+        owner[b] = best; load[best] += std::max<uint64_t>(sizes[b], 1);
+    }
+    return owner;
+}
+
+// all-to-all(v) of bytes between the N rank threads of this process.  The sizes travel through host memory (the threads share an
+// address space: one barrier, no collective), the segments through ONE RCCL group per rank and exchange — stream-ordered, nothing
+// waits for them — or, when two ranks share a device (tests) or --transport copy, by device-to-device copies.
 class Exchange
 {
 public:
     Exchange(const std::vector<int> & devices, bool useRccl) : n_((unsigned)devices.size()), devices_(devices), barrier_((unsigned)devices.size()),
-        sendPtr_(devices.size(), nullptr), counts_(devices.size() * devices.size(), 0), sums_(), useRccl_(useRccl)
+        sendPtr_(devices.size(), nullptr), useRccl_(useRccl)
     {
         if (useRccl_)
         {
@@ -101,72 +127,116 @@ public:
     bool rccl() const { return useRccl_; }
     unsigned ranks() const { return n_; }
 
-    // Called by every rank thread with its own arguments.  `send`: device buffer, the segments for ranks 0..N-1 back to back, sendBytes[d] each.
-    // `recv` receives the segments of ranks 0..N-1 back to back; recvBytes[s] = bytes that came from rank s.
-    void allToAll(unsigned rank, hipStream_t st, const void * send, const std::vector<size_t> & sendBytes, RankBuf & recv, std::vector<size_t> & recvBytes)
+    // Every rank gives the N rows it has for ranks 0..N-1 (host memory, rowBytes each) and gets the rows the others have for it.
+    // Rows live in one of two generations of a shared matrix: a rank can be at most one exchange ahead of the slowest one (each
+    // exchange contains a barrier), so the rows of exchange g are read before anybody writes generation g + 2.
+    void exchangeRows(unsigned rank, const void * mine, size_t rowBytes, void * theirs)
     {
-        sendPtr_[rank] = send;
-        for (unsigned d = 0; d < n_; ++d) counts_[rank * n_ + d] = sendBytes[d];
-        barrier_.wait();                                    // every rank has published its buffer and counts
-        recvBytes.assign(n_, 0);
+        std::vector<uint8_t> & M = rows_[gen_[rank] & 1];
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (M.size() < (size_t)n_ * n_ * rowBytes) M.resize((size_t)n_ * n_ * rowBytes);
+        }
+        barrier_.wait();                                    // the matrix has its size (and the previous user of this generation is done with it)
+        memcpy(M.data() + (size_t)rank * n_ * rowBytes, mine, (size_t)n_ * rowBytes);
+        barrier_.wait();                                    // every rank has published
+        for (unsigned s = 0; s < n_; ++s) memcpy((uint8_t *)theirs + s * rowBytes, M.data() + ((size_t)s * n_ + rank) * rowBytes, rowBytes);
+        ++gen_[rank];
+    }
+
+    // A failure of one rank between the two halves of an exchange must not leave its peers waiting for data that never comes: every rank
+    // reports whether it is ready to transfer (its receive buffer is allocated), and ALL ranks throw if any is not — before any transfer
+    // is queued.
+    void agree(unsigned rank, bool ok)
+    {
+        (void)rank;
+        { std::lock_guard<std::mutex> lk(m_); if (!ok) ++failed_; }
+        barrier_.wait();
+        const bool bad = failed_ != 0;
+        barrier_.wait();                                    // everybody has read the verdict
+        if (bad) throw GpuError("a rank could not prepare its side of the exchange");
+    }
+
+    // Called by every rank thread with its own arguments.  `send`: device buffer, the segments for ranks 0..N-1 back to back, sendBytes[d] each;
+    // `recv`: the segments of ranks 0..N-1 back to back, recvBytes[s] = bytes from rank s (both known from exchangeRows).  The transfer is
+    // queued on `st`; with RCCL nothing waits for it (work queued on `st` afterwards sees the data, and the send buffer may be overwritten
+    // by work queued on `st`).  An error inside the RCCL section cannot be made collective any more — peers may already be waiting on the
+    // device — so it ends the process (exit code 1): never retried.
+    void allToAll(unsigned rank, hipStream_t st, const void * send, const std::vector<size_t> & sendBytes, RankBuf & recv, const std::vector<size_t> & recvBytes)
+    {
         size_t total = 0;
-        for (unsigned s = 0; s < n_; ++s) { recvBytes[s] = counts_[s * n_ + rank]; total += recvBytes[s]; }
-        recv.reserve(total + 16);
+        for (unsigned s = 0; s < n_; ++s) total += recvBytes[s];
+        bool ok = true;
+        try { recv.reserve(total + 16); } catch (std::exception const &) { ok = false; }
+        if (failNextReserve_ == (int)rank) { ok = false; failNextReserve_ = -1; }        // fault injection (tests/native/exchange_fail.cpp)
+        sendPtr_[rank] = send;
+        { std::lock_guard<std::mutex> lk(m_); if (sendOffs_.size() != (size_t)n_ * n_) sendOffs_.assign((size_t)n_ * n_, 0); }
+        agree(rank, ok);
         if (useRccl_)
         {
-            rccl_.check(rccl_.GroupStart(), "ncclGroupStart");
-            size_t so = 0, ro = 0;
-            for (unsigned p = 0; p < n_; ++p)
+            try
             {
-                if (sendBytes[p]) rccl_.check(rccl_.Send((const char *)send + so, sendBytes[p], RcclApi::Uint8, (int)p, comms_[rank], st), "ncclSend");
-                if (recvBytes[p]) rccl_.check(rccl_.Recv((char *)recv.p + ro, recvBytes[p], RcclApi::Uint8, (int)p, comms_[rank], st), "ncclRecv");
-                so += sendBytes[p]; ro += recvBytes[p];
+                rccl_.check(rccl_.GroupStart(), "ncclGroupStart");
+                size_t so = 0, ro = 0;
+                for (unsigned p = 0; p < n_; ++p)
+                {
+                    if (sendBytes[p]) rccl_.check(rccl_.Send((const char *)send + so, sendBytes[p], RcclApi::Uint8, (int)p, comms_[rank], st), "ncclSend");
+                    if (recvBytes[p]) rccl_.check(rccl_.Recv((char *)recv.p + ro, recvBytes[p], RcclApi::Uint8, (int)p, comms_[rank], st), "ncclRecv");
+                    so += sendBytes[p]; ro += recvBytes[p];
+                }
+                rccl_.check(rccl_.GroupEnd(), "ncclGroupEnd");
             }
-            rccl_.check(rccl_.GroupEnd(), "ncclGroupEnd");
+            catch (std::exception const & e)
+            {
+                fprintf(stderr, "dream_yara_mapper: rank %u: %s — peers may already wait for this transfer on their devices; exiting\n", rank, e.what());
+                fflush(stderr);
+                barrier_.abort();
+                _exit(1);
+            }
         }
         else
         {   // pull: every rank copies its segment out of each source's buffer (peer copy over xGMI, or inside one device)
+            size_t acc = 0;
+            for (unsigned d = 0; d < n_; ++d) { sendOffs_[(size_t)rank * n_ + d] = acc; acc += sendBytes[d]; }
+            barrier_.wait();                                // every rank has published its buffer and offsets, and its packing is queued ...
+            hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize (exchange)");
+            barrier_.wait();                                // ... and done
             size_t ro = 0;
             for (unsigned s = 0; s < n_; ++s)
             {
-                size_t so = 0;
-                for (unsigned d = 0; d < rank; ++d) so += counts_[s * n_ + d];
-                if (recvBytes[s]) hipCheck(hipMemcpyAsync((char *)recv.p + ro, (const char *)sendPtr_[s] + so, recvBytes[s], hipMemcpyDefault, st), "hipMemcpyAsync (exchange)");
+                if (recvBytes[s]) hipCheck(hipMemcpyAsync((char *)recv.p + ro, (const char *)sendPtr_[s] + sendOffs_[(size_t)s * n_ + rank], recvBytes[s], hipMemcpyDefault, st), "hipMemcpyAsync (exchange)");
                 ro += recvBytes[s];
             }
+            hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize (exchange)");
+            barrier_.wait();                                // the send buffers may be reused from here on
         }
-        hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize (exchange)");
-        barrier_.wait();                                    // the send buffers may be reused from here on
-    }
-
-    // element-wise sum over the ranks (host values; every rank gets the result)
-    void allReduceSum(unsigned rank, std::vector<uint32_t> & v)
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            if (sums_.size() != v.size()) sums_.assign(v.size(), 0);
-            for (size_t i = 0; i < v.size(); ++i) sums_[i] += v[i];
-        }
-        barrier_.wait();
-        v = sums_;
-        barrier_.wait();
-        if (rank == 0) sums_.assign(sums_.size(), 0);
-        barrier_.wait();
     }
     void barrier() { barrier_.wait(); }
     void abort() { barrier_.abort(); }
+    void injectReserveFailure(int rank) { failNextReserve_ = rank; }
 
 private:
     unsigned n_;
     std::vector<int> devices_;
     ThreadBarrier barrier_;
     std::vector<const void *> sendPtr_;
-    std::vector<size_t> counts_;
-    std::vector<uint32_t> sums_;
+    std::vector<size_t> sendOffs_;
+    std::vector<uint8_t> rows_[2];
+    unsigned gen_[64] = {};
+    unsigned failed_ = 0;
+    int failNextReserve_ = -1;
     std::mutex m_;
     bool useRccl_;
     RcclApi rccl_;
     std::vector<RcclApi::comm_t> comms_;
+};
+
+// pinned host memory for the rows a rank fetches from its device (two small copies per batch)
+struct PinnedRows
+{
+    void * p = nullptr; size_t cap = 0;
+    void reserve(size_t bytes) { if (bytes <= cap) return; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; hipCheck(hipHostMalloc(&p, bytes + 256, hipHostMallocDefault), "hipHostMalloc"); cap = bytes + 256; }
+    ~PinnedRows() { if (p) (void)hipHostFree(p); }
 };
 
 // One rank of a bins-sharded job: the per-batch sequence of include/dyhip.h ("bins sharded over ranks").
@@ -176,60 +246,56 @@ struct ShardRank
     dy_ctx * ctx = nullptr; dy_ibf * ibf = nullptr; dy_index * idx = nullptr;
     uint32_t nBins = 0, W = 0;
     std::vector<uint64_t> ownerMasks;        // nRanks x W
-    RankBuf ids, lens, masks, seqs, rIds, rLens, rMasks, rSeqs, raw, rRaw, items, rItems;
+    RankBuf rowsDev, recv1, recv2;
+    PinnedRows rowsHost;
 
     static void check(int rc) { if (rc != DY_OK) throw GpuError(dy_last_error()); }
 
     // `reads`: this rank's home reads, bin masks already on them (dy_ibf_query, or every bin for -ft none).  Returns the home result.
+    // Host synchronisations per batch: one per exchange (the sizes), those inside dy_map_bins, one at the end.
     dy_result * mapBatch(Exchange & ex, dy_reads * reads, const dy_params & prm)
     {
         hipStream_t st = (hipStream_t)dy_ctx_stream(ctx);
         const bool paired = prm.paired != 0;
-        std::vector<uint32_t> nTo(nRanks); std::vector<uint64_t> bTo(nRanks);
-        check(dy_shard_plan(ctx, reads, nRanks, ownerMasks.data(), paired ? 1u : 0u, nTo.data(), bTo.data()));
-        size_t nTot = 0, bTot = 0;
-        for (unsigned d = 0; d < nRanks; ++d) { nTot += nTo[d]; bTot += bTo[d]; }
-        for (RankBuf * b : {&ids, &lens, &masks, &seqs, &rIds, &rLens, &rMasks, &rSeqs, &raw, &rRaw, &items, &rItems}) b->device = device;
-        ids.reserve(nTot * 4 + 16); lens.reserve(nTot * 4 + 16); masks.reserve(nTot * W * 8 + 16); seqs.reserve(bTot + 16);
-        check(dy_shard_pack(ctx, reads, ids.p, lens.p, masks.p, seqs.p));
-        std::vector<size_t> sb(nRanks), rb;
-        for (unsigned d = 0; d < nRanks; ++d) sb[d] = (size_t)nTo[d] * 4;
-        std::vector<size_t> rIdBytes;
-        ex.allToAll(rank, st, ids.p, sb, rIds, rIdBytes);
-        ex.allToAll(rank, st, lens.p, sb, rLens, rb);
-        for (unsigned d = 0; d < nRanks; ++d) sb[d] = (size_t)nTo[d] * W * 8;
-        ex.allToAll(rank, st, masks.p, sb, rMasks, rb);
-        for (unsigned d = 0; d < nRanks; ++d) sb[d] = (size_t)bTo[d];
-        ex.allToAll(rank, st, seqs.p, sb, rSeqs, rb);
-        size_t nRecv = 0, basesRecv = 0;
-        std::vector<uint32_t> seg(nRanks + 1, 0);
-        for (unsigned s = 0; s < nRanks; ++s) { nRecv += rIdBytes[s] / 4; seg[s + 1] = (uint32_t)nRecv; basesRecv += rb[s]; }
+        for (RankBuf * b : {&rowsDev, &recv1, &recv2}) b->device = device;
+        hipCheck(hipSetDevice(device), "hipSetDevice");
+        const size_t row2 = dy_shard_c2_row_bytes(nBins), rowMax = std::max(row2, sizeof(dy_seg_header));
+        rowsDev.reserve(nRanks * rowMax); rowsHost.reserve(2 * nRanks * rowMax);
+        uint8_t * mine = (uint8_t *)rowsHost.p, * theirs = mine + nRanks * rowMax;
+        std::vector<size_t> sb(nRanks), rb(nRanks);
+
+        // [C1] reads -> owners of their selected bins
+        void * send = nullptr;
+        check(dy_shard_c1_pack(ctx, reads, nRanks, ownerMasks.data(), paired ? 1u : 0u, rowsDev.p, &send));
+        hipCheck(hipMemcpyAsync(mine, rowsDev.p, nRanks * sizeof(dy_seg_header), hipMemcpyDeviceToHost, st), "hipMemcpyAsync (headers)");
+        hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize (headers)");
+        ex.exchangeRows(rank, mine, sizeof(dy_seg_header), theirs);
+        std::vector<dy_seg_header> in(nRanks);
+        memcpy(in.data(), theirs, nRanks * sizeof(dy_seg_header));
+        for (unsigned d = 0; d < nRanks; ++d) { sb[d] = (size_t)((const dy_seg_header *)mine)[d].bytes; rb[d] = (size_t)in[d].bytes; }
+        ex.allToAll(rank, st, send, sb, recv1, rb);
         dy_reads * sub = nullptr;
-        if (paired) check(dy_reads_from_device_paired(ctx, rSeqs.p, rLens.p, rMasks.p, (uint32_t)nRecv, basesRecv, nBins, nRanks, seg.data(), &sub));
-        else check(dy_reads_from_device(ctx, rSeqs.p, rLens.p, rMasks.p, (uint32_t)nRecv, basesRecv, nBins, &sub));
-        std::vector<uint32_t> loads(nBins, 0); uint64_t nRaw = 0;
-        check(dy_map_bins(ctx, idx, sub, &prm, loads.data(), &nRaw));
-        raw.reserve(nRaw * DY_RAW_MATCH_BYTES + 16);
-        std::vector<uint64_t> rawTo(nRanks, 0), itemsTo(nRanks, 0);
-        check(dy_raw_pack(ctx, nRanks, seg.data(), rIds.p, raw.p, rawTo.data()));
-        size_t nItemsIn = 0;
-        if (paired)
-        {
-            size_t nItems = 0; for (uint32_t l : loads) nItems += l;
-            items.reserve(nItems * DY_PE_ITEM_BYTES + 16);
-            check(dy_pe_items_pack(ctx, nRanks, seg.data(), rIds.p, items.p, itemsTo.data()));
-            for (unsigned d = 0; d < nRanks; ++d) sb[d] = (size_t)itemsTo[d] * DY_PE_ITEM_BYTES;
-            ex.allToAll(rank, st, items.p, sb, rItems, rb);
-            for (size_t b : rb) nItemsIn += b / DY_PE_ITEM_BYTES;
-        }
+        check(dy_shard_c1_unpack(ctx, recv1.p, nRanks, in.data(), nBins, paired ? 1u : 0u, &sub));
+        int rc = dy_map_bins(ctx, idx, sub, &prm, nullptr, nullptr);
+        if (rc != DY_OK) { dy_reads_free(sub); check(rc); }
+
+        // [C2] raw matches (+ pairing records) -> the read's home rank; the rows also carry the items per bin (sortedBins(), reference src/d_mapper.h:843-854)
+        rc = dy_shard_c2_pack(ctx, rowsDev.p, &send);
         dy_reads_free(sub);
-        for (unsigned d = 0; d < nRanks; ++d) sb[d] = (size_t)rawTo[d] * DY_RAW_MATCH_BYTES;
-        ex.allToAll(rank, st, raw.p, sb, rRaw, rb);
-        size_t nRawIn = 0; for (size_t b : rb) nRawIn += b / DY_RAW_MATCH_BYTES;
-        ex.allReduceSum(rank, loads);                          // sortedBins() over the whole job (reference src/d_mapper.h:843-854)
+        check(rc);
+        hipCheck(hipMemcpyAsync(mine, rowsDev.p, nRanks * row2, hipMemcpyDeviceToHost, st), "hipMemcpyAsync (rows)");
+        hipCheck(hipStreamSynchronize(st), "hipStreamSynchronize (rows)");
+        ex.exchangeRows(rank, mine, row2, theirs);
+        for (unsigned d = 0; d < nRanks; ++d)
+        {
+            dy_seg_header h; memcpy(&h, mine + d * row2, sizeof(h)); sb[d] = (size_t)h.bytes;
+            memcpy(&h, theirs + d * row2, sizeof(h)); rb[d] = (size_t)h.bytes;
+        }
+        ex.allToAll(rank, st, send, sb, recv2, rb);
         dy_result * res = nullptr;
-        check(dy_finalize_raw(ctx, idx, reads, &prm, rRaw.p, nRawIn, nItemsIn ? rItems.p : nullptr, nItemsIn, loads.data(), &res));
-        check(dy_result_fetch(res));
+        check(dy_shard_finalize(ctx, idx, reads, &prm, recv2.p, nRanks, theirs, &res));
+        rc = dy_result_fetch(res);
+        if (rc != DY_OK) { dy_result_free(res); check(rc); }
         return res;
     }
 };

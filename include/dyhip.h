@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define DY_ABI_VERSION 2
+#define DY_ABI_VERSION 3
 
 enum {
     DY_OK = 0,
@@ -115,7 +115,7 @@ void dy_reads_free(dy_reads *r);
 int  dy_ibf_query(dy_ibf *f, dy_reads *reads, uint16_t threshold, uint64_t *bin_masks_host);
 
 /* `-ft none`: every read goes to every bin (reference src/d_mapper.h:399-405) — sets the masks dy_ibf_query would set.  dy_map_reads does
- * this by itself when use_filter = 0; the bins-sharded sequence (dy_shard_plan ...) needs the masks on the reads first. */
+ * this by itself when use_filter = 0; the bins-sharded sequence (dy_shard_c1_pack ...) needs the masks on the reads first. */
 int  dy_reads_select_all_bins(dy_ctx *ctx, dy_reads *reads, uint32_t n_bins);
 
 /* ---- index ------------------------------------------------------------------------------------------- */
@@ -148,7 +148,7 @@ int  dy_suffix_array(dy_ctx *ctx, const uint32_t *text, uint64_t n, uint32_t sig
 typedef struct {
     float    error_rate;      /* Options::errorRate  (reference src/mapper.h:68,99)  */
     float    strata_rate;     /* Options::strataRate (:70,101) */
-    uint32_t sensitivity;     /* 0 low, 1 high (2 = full/edit-distance seeds: DY_EUNSUPPORTED) (:72,103) */
+    uint32_t sensitivity;     /* 0 low, 1 high, 2 full (edit-distance seeds, Options::sensitivity FULL) (:72,103) */
     uint32_t hits_threshold;  /* Options::hitsThreshold (:84,111), default 300 */
     uint32_t use_filter;      /* 0 = -ft none: every read goes to every bin (reference src/d_mapper.h:399-405) */
     uint32_t paired;          /* 1 = paired-end: reads [0,n/2) are the first mates, [n/2,n) the second mates (reference src/bits_reads.h) */
@@ -212,55 +212,61 @@ typedef struct {
 } dy_map_stats;
 int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
 
-/* ---- bins sharded over ranks (one process per GPU) -------------------------------------------------------
+/* ---- bins sharded over ranks (one process or host thread per GPU) -----------------------------------------
  * The reference's unit of distribution is the bin (src/d_mapper.h:876-884: one child Mapper per bin; copyMatches
  * :127-155, copyCigars :186-215 and finalizeMainMapper :828-838 merge per read).  With G ranks every rank holds the filter,
  * the contig text of ALL bins (the home rank of a read aligns its primary) and the FM structures of the bins it owns.
- * A batch step on rank r, with the exchanges done by the caller (RCCL / MPI all-to-all on caller-owned DEVICE buffers;
- * the library never communicates):
- *   dy_ibf_query(home reads)                              K1 on the rank's own reads
- *   dy_shard_plan / dy_shard_pack                         [C1] reads selected for each owner rank  -> all-to-all
- *   dy_reads_from_device(_paired) + dy_map_bins           K2+K3 on the owner, for its bins only (paired: + the child mapper's
- *                                                         pairing, library statistics and mate rescue, which are bin-local)
- *   dy_raw_pack (+ dy_pe_items_pack)                      [C2] raw matches (+ per-(read,bin) pairing records) -> the read's home
- *   dy_finalize_raw(home reads, raw matches, records, global bin loads)   K4 = aggregate + rankMatches2 on the home rank
- * `bin_loads` (items per bin, summed over ranks by the caller) orders the bins like sortedBins() (:843-854) does.
+ * The library never communicates: it packs each of the two exchanges into ONE device buffer (segments destination-major) plus
+ * one small row of counts per destination, and unpacks what the caller received.  The CALLER exchanges the rows, fetches them
+ * to the host (its one stream synchronisation per exchange: the sizes of an all-to-all(v) are host arguments) and moves the
+ * segments (RCCL ncclSend/ncclRecv group, MPI, peer copies) — stream-ordered on dy_ctx_stream(), nothing else waits:
+ *   dy_ibf_query(home reads)                                       K1 on the rank's own reads
+ *   dy_shard_c1_pack            [C1] reads selected for each owner rank: headers (G x 32 B) + packed segments
+ *       -> all-to-all of the headers, fetch, all-to-all(v) of the segments
+ *   dy_shard_c1_unpack + dy_map_bins                               K2+K3 on the owner, for its bins only (paired: + the child mapper's
+ *                                                                  pairing, library statistics and mate rescue, which are bin-local)
+ *   dy_shard_c2_pack            [C2] raw matches (+ pairing records) for each read's home rank: rows (G x dy_shard_c2_row_bytes) + segments;
+ *                               every row also carries this rank's items per bin, which the receivers add up (sortedBins(), :843-854)
+ *       -> all-to-all of the rows, fetch, all-to-all(v) of the segments
+ *   dy_shard_finalize(home reads, received segments, received rows)   K4 = aggregate + rankMatches2 on the home rank
  * Results equal dy_map_reads on the concatenation of all ranks' reads; for a paired job the concatenation is
- * [first mates of rank 0, first mates of rank 1, ... | second mates of rank 0, ...] (mates stay together: src/d_mapper.h:350-358). */
+ * [first mates of rank 0, first mates of rank 1, ... | second mates of rank 0, ...] (mates stay together: src/d_mapper.h:350-358).
+ * With one rank the packed send buffer IS the receive buffer (no copy, no communication). */
 
 /* Like dy_index_load, but FM structures only for bins with owned[b] != 0 (contigs and names for all). */
 int  dy_index_load_sharded(dy_ctx *ctx, const char *dir, uint32_t n_bins, const uint8_t *owned, dy_index **out);
-/* owner_masks: n_ranks x W words (host), rank d's bit set of owned bins.  paired != 0: `reads` holds first mates then second mates
- * and the masks of the two mates are OR-ed first, so both travel wherever either is selected.  Out (host, n_ranks entries each):
- * how many of `reads` have a selected bin on rank d, and their total bases.  loadFilteredReads — reference src/d_mapper.h:394-443. */
-int  dy_shard_plan(dy_ctx *ctx, const dy_reads *reads, uint32_t n_ranks, const uint64_t *owner_masks, uint32_t paired,
-                   uint32_t *n_reads_to, uint64_t *n_bases_to);
-/* Fills the caller's DEVICE buffers, destination-major, in read order inside a destination: ids (u32 read id on this
- * rank), lens (u32), masks (W words per read, restricted to the destination's bins), seqs (forward Dna5 codes). */
-int  dy_shard_pack(dy_ctx *ctx, const dy_reads *reads, void *ids_dev, void *lens_dev, void *masks_dev, void *seqs_dev);
-/* A reads batch from DEVICE buffers in the layout dy_shard_pack writes (n reads, n_bases bases, W mask words per read). */
-int  dy_reads_from_device(dy_ctx *ctx, const void *seqs_dev, const void *lens_dev, const void *masks_dev,
-                          uint32_t n_reads, uint64_t n_bases, uint32_t n_bins, dy_reads **out);
-/* Same for a paired job: reads [seg_starts[s], seg_starts[s+1]) arrived from rank s (an even number: that rank's selected
- * first mates, then their second mates); the batch is re-ordered to [all first mates | all second mates], pairs in source
- * order, which is what the child mapper sees in the reference (src/d_mapper.h:394-443). */
-int  dy_reads_from_device_paired(dy_ctx *ctx, const void *seqs_dev, const void *lens_dev, const void *masks_dev,
-                                 uint32_t n_reads, uint64_t n_bases, uint32_t n_bins, uint32_t n_ranks, const uint32_t *seg_starts, dy_reads **out);
+
+/* One row per peer rank.  C1: reads / bases in the segment, aux = longest | shortest << 32 read length of the sender's batch (bounds).
+ * C2: n_reads = raw matches, n_bases = pairing records in the segment.  `bytes` = size of the segment (a multiple of 16). */
+typedef struct { uint64_t n_reads, n_bases, bytes, aux; } dy_seg_header;
+
+/* [C1] loadFilteredReads across ranks — reference src/d_mapper.h:394-443.  owner_masks: n_ranks x W words (host), rank d's bit set of
+ * owned bins.  paired != 0: `reads` holds first mates then second mates and the masks of the two mates are OR-ed first, so both
+ * travel wherever either is selected.  Queues the packing on the context's stream and returns at once:
+ *   headers_dev (DEVICE, caller-owned, n_ranks x dy_seg_header): row d describes the segment for rank d;
+ *   *send_dev: the context's packed buffer, segments for ranks 0..n_ranks-1 back to back — per segment the read ids on this rank
+ *   (u32), lengths (u32), masks restricted to the destination's bins (W words per read), forward Dna5 codes; valid until the next call. */
+int  dy_shard_c1_pack(dy_ctx *ctx, dy_reads *reads, uint32_t n_ranks, const uint64_t *owner_masks, uint32_t paired, void *headers_dev, void **send_dev);
+/* The owner-side batch from the segments received from ranks 0..n_ranks-1 (recv_dev: DEVICE, back to back; recv_headers: HOST, the rows
+ * the sources sent for this rank).  A paired batch is re-ordered to [all first mates | all second mates], pairs in source order,
+ * which is what the child mapper sees in the reference (src/d_mapper.h:394-443).  Queued on the stream, no host synchronisation;
+ * recv_dev may be reused once work queued after this call has started. */
+int  dy_shard_c1_unpack(dy_ctx *ctx, const void *recv_dev, uint32_t n_ranks, const dy_seg_header *recv_headers, uint32_t n_bins, uint32_t paired, dy_reads **out);
 /* K2 + K3 over the (read,bin) items of the masks; with p->paired also the bin-local pairing stages of the child mapper
- * (reference src/mapper.h:927-1172).  bin_loads (host, n_bins) receives the items per bin; the raw matches (and pairing
- * records) stay in the context until dy_raw_pack / dy_pe_items_pack. */
+ * (reference src/mapper.h:927-1172).  bin_loads (host, n_bins; may be NULL) receives the items per bin, n_raw (may be NULL) the
+ * number of raw matches; they (and the pairing records) stay in the context until dy_shard_c2_pack. */
 int  dy_map_bins(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, uint32_t *bin_loads, uint64_t *n_raw);
-/* Rewrites the read id of every raw match of the last dy_map_bins through ids_dev (indexed by arrival order) and orders them
- * by source rank: reads [seg_starts[s], seg_starts[s+1]) came from rank s.  raw_out_dev: n_raw x 16 B (DEVICE); n_raw_to: host. */
-int  dy_raw_pack(dy_ctx *ctx, uint32_t n_ranks, const uint32_t *seg_starts, const void *ids_dev, void *raw_out_dev, uint64_t *n_raw_to);
-/* Paired jobs: one DY_PE_ITEM_BYTES record per (read,bin) item of the last dy_map_bins that carries information — the child's
- * primary as chosen by the pairing, `paired`, the pair probability, a rescued mate (what copyCigars ships, reference
- * src/d_mapper.h:186-215) — ordered by source rank like dy_raw_pack.  items_out_dev must hold sum(bin_loads) records. */
-int  dy_pe_items_pack(dy_ctx *ctx, uint32_t n_ranks, const uint32_t *seg_starts, const void *ids_dev, void *items_out_dev, uint64_t *n_items_to);
-/* K4 on the home rank over raw matches gathered from all owners (DEVICE, 16 B each); paired jobs also pass the gathered
- * pairing records (pe_items_dev, n_pe_items; NULL / 0 for single-end). */
-int  dy_finalize_raw(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, const void *raw_dev, uint64_t n_raw,
-                     const void *pe_items_dev, uint64_t n_pe_items, const uint32_t *bin_loads, dy_result **out);
+/* [C2] copyMatches / copyCigars across ranks — reference src/d_mapper.h:127-215.  Bytes of one row: a dy_seg_header + n_bins x u32 (padded to 8). */
+size_t dy_shard_c2_row_bytes(uint32_t n_bins);
+/* After dy_map_bins on a batch of dy_shard_c1_unpack: rewrites the read id of every raw match to the id on its home rank and packs
+ * the matches (16 B each; paired jobs: then one DY_PE_ITEM_BYTES record per (read,bin) item that carries information — the child's
+ * primary as chosen by the pairing, `paired`, the pair probability, a rescued mate) by home rank.  rows_dev (DEVICE, caller-owned,
+ * n_ranks rows); *send_dev: the context's packed buffer.  Queued on the stream, no host synchronisation. */
+int  dy_shard_c2_pack(dy_ctx *ctx, void *rows_dev, void **send_dev);
+/* K4 on the home rank over the segments gathered from all owners (recv_dev: DEVICE; recv_rows: HOST, the rows the owners sent for this
+ * rank).  Returns like dy_map_reads_async. */
+int  dy_shard_finalize(dy_ctx *ctx, const dy_index *idx, dy_reads *reads, const dy_params *p, const void *recv_dev, uint32_t n_ranks,
+                       const void *recv_rows, dy_result **out);
 #define DY_RAW_MATCH_BYTES 16
 #define DY_PE_ITEM_BYTES 40
 

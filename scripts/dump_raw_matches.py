@@ -1,4 +1,4 @@
-"""Dumps the sorted raw matches of K3 (dy_map_bins) on the repeat-rich test data, with the library named by DY_LIB:
+"""Dumps the sorted raw matches of K3 (dy_map_bins through the one-rank packed exchange) on the repeat-rich test data, with the library named by DY_LIB:
     DY_LIB=.../libdyhip_a.so python scripts/dump_raw_matches.py a /tmp/x; DY_LIB=.../libdyhip_b.so python scripts/dump_raw_matches.py b /tmp/x
 then compare /tmp/x/raw_a_0.npy with raw_b_0.npy (A/B check of an extension-kernel change, independent of the finalize stage)."""
 import os, sys, subprocess
@@ -32,14 +32,10 @@ ibf = dy.Ibf.load(ctx, os.path.join(tmp, "f.filter"))
 n = offs.size - 1
 thr = dy.threshold(np.float32(e / 100.0), ibf.info()["kmer_size"], int(int(offs[-1]) // n))
 ibf.query(reads, thr, want_masks=False)
+from dream_yara_amd import sharded
 for rep in range(3):
-    loads, n_raw = dy.map_bins(ctx, idx, reads, params)
-    raw = torch.empty(n_raw * dy.RAW_MATCH_BYTES, dtype=torch.uint8, device="cuda:0")
-    ids = torch.arange(n, dtype=torch.int32, device="cuda:0")
-    torch.cuda.synchronize()
-    dy.raw_pack(ctx, np.array([0, n], np.uint32), ids.data_ptr(), raw.data_ptr())
-    torch.cuda.synchronize()
-    a = raw.cpu().numpy().view([("read", "<u4"), ("begin", "<u4"), ("len", "<u2"), ("errors", "u1"), ("strand", "u1"), ("bin", "<u2"), ("contig", "<u2")])
+    a, loads = sharded.raw_matches(ctx, idx, reads, params, n_bins)
+    n_raw = a.size
     a = np.sort(a, order=["read", "bin", "contig", "strand", "begin", "len", "errors"])
     np.save(os.path.join(tmp, "raw_%s_%d.npy" % (tag, rep)), a)
     print(tag, rep, "items", int(loads.sum()), "raw", n_raw, flush=True)

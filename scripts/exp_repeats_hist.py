@@ -19,13 +19,9 @@ n = offs.size - 1
 ctx = dy.Context(0); idx = dy.Index(ctx, idx_dir, n_bins); rd = dy.Reads(ctx, codes, offs)
 params = dy.default_params(error_rate=np.float32(0.03)); params.use_filter = 0
 res = dy.map_reads(ctx, idx, rd, params); res.close()          # fills the all-bins masks
-loads, n_raw = dy.map_bins(ctx, idx, rd, params)
-raw = torch.empty(n_raw * dy.RAW_MATCH_BYTES, dtype=torch.uint8, device="cuda:0")
-ids = torch.arange(n, dtype=torch.int32, device="cuda:0")
-torch.cuda.synchronize()
-dy.raw_pack(ctx, np.array([0, n], np.uint32), ids.data_ptr(), raw.data_ptr())
-torch.cuda.synchronize()
-a = raw.cpu().numpy().view([("read", "<u4"), ("begin", "<u4"), ("len", "<u2"), ("errors", "u1"), ("strand", "u1"), ("bin", "<u2"), ("contig", "<u2")])
+from dream_yara_amd import sharded
+a, loads = sharded.raw_matches(ctx, idx, rd, params, n_bins)
+n_raw = a.size
 cnt = np.bincount(a["read"], minlength=n)
 print("raw", n_raw, "reads", n, "max", cnt.max(), "percentiles 50/90/99/99.9:", [int(np.percentile(cnt, p)) for p in (50, 90, 99, 99.9)])
 for lo, hi in ((0, 1), (2, 64), (65, 2048), (2049, 4096), (4097, 16384), (16385, 1 << 30)):

@@ -30,7 +30,7 @@ def test_python_binding_covers_header(product_build):
     import dream_yara_amd as dy
     bound = sorted(name for name, _, _ in dy.SYMBOLS)
     assert bound == _declared_symbols()
-    assert dy.load_library().dy_abi_version() == 2
+    assert dy.load_library().dy_abi_version() == 3
 
 
 def test_no_device_fails_loudly(product_build):
