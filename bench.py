@@ -167,7 +167,9 @@ def main():
     ap.add_argument("--paired", action="store_true", help="paired-end batch: reads/2 pairs of 2 x L bp, insert N(400, 40) (BASELINE configs[3]); not the default metric")
     ap.add_argument("--shard", default="both", choices=["both", "reads", "bins"], help="what is partitioned across ranks (see module docstring); at N = 1 'both' means reads")
     ap.add_argument("--bins-leg-timeout", type=float, default=300.0, help="seconds after which the bins-sharded leg of --shard both is given up (the line is printed without it)")
-    ap.add_argument("--no-prefetch", action="store_true", help="bins-sharded leg: do not queue the next batch's IBF sweep under the current batch's exchanges")
+    ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
+                    help="bins-sharded leg: queue the next batch's IBF sweep in chunks in front of the host's waits (count fetches, peers).  auto = on with more than one rank "
+                         "(on one GPU the waits are short: 5.96 ms per step without, 6.00 ms with, profiles/r03_*)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dy_ctx_set_tuning knob for experiments (result-identical code paths; see include/dyhip.h)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
@@ -240,7 +242,7 @@ def main():
         t_load = time.time()
         if mode == "bins":
             from dream_yara_amd import sharded
-            sm = sharded.ShardedMapper(ctx, grp.dist, rank, world, idx_dir, wl["bins"], ibf, "cuda", prefetch=not args.no_prefetch)
+            sm = sharded.ShardedMapper(ctx, grp.dist, rank, world, idx_dir, wl["bins"], ibf, "cuda", prefetch=args.prefetch == "on" or (args.prefetch == "auto" and world > 1))
             index = sm.index
         else:
             index = dy.Index(ctx, idx_dir, wl["bins"])

@@ -87,6 +87,8 @@ SYMBOLS = [
     ("dy_reads_count", C.c_uint32, [_P]),
     ("dy_reads_free", None, [_P]),
     ("dy_ibf_query", C.c_int, [_P, _P, C.c_uint16, _P]),
+    ("dy_ibf_query_deferred", C.c_int, [_P, _P, C.c_uint16]),
+    ("dy_ctx_background_chunk", C.c_int, [_P, C.c_uint32]),
     ("dy_reads_select_all_bins", C.c_int, [_P, _P, C.c_uint32]),
     ("dy_suffix_array", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P]),
     ("dy_index_load", C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(_P)]),
@@ -159,6 +161,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.dy_ctx_sync(self.h))
+
+    def background_chunk(self, max_reads=0):
+        """One chunk of the pending deferred sweep, to be called right before waiting for an event recorded on the context's stream."""
+        _check(self.lib.dy_ctx_background_chunk(self.h, max_reads))
 
     def stream(self):
         """The context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)."""
@@ -238,6 +244,10 @@ class Ibf:
         masks = np.empty((reads.n, W), dtype=np.uint64) if want_masks else None
         _check(self.lib.dy_ibf_query(self.h, reads.h, threshold, masks.ctypes.data if want_masks else None))
         return masks
+
+    def query_deferred(self, reads, threshold):
+        """The sweep of the batch mapped NEXT: queued in chunks in front of the host's waits while the current batch is mapped."""
+        _check(self.lib.dy_ibf_query_deferred(self.h, reads.h, threshold))
 
     def close(self):
         if self.h:

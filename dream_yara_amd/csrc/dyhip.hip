@@ -131,11 +131,20 @@ struct Tuning
     u64 dpSmallBlocks = 4096;   // grid of the thread-level aggregation kernels (k_finalize_small, k_pe_*): list-driven, grid-stride
     u64 dpAlignBlocks = 8192;   // grid of k_align_single
     u64 itemsSorted = 1;        // work list: 1 = (bin, read) pairs in read order + stable radix sort by bin, 0 = bin-major count matrix + scan + scatter
+    u64 sweepChunk = 16384;     // reads per chunk of a deferred sweep (dy_ibf_query_deferred): ~60 us of K1, about one host round trip
 };
+
+struct dy_ibf; struct dy_reads;
+// dy_ibf_query_deferred: the sweep of the batch mapped next, launched chunk by chunk in front of the host's waits
+struct PendingSweep { dy_ibf * f = nullptr; dy_reads * reads = nullptr; u32 threshold = 0, next = 0, slot = 0; };
+struct SweepTiming { enum { MAX_CHUNKS = 24 }; hipEvent_t ev[2 * MAX_CHUNKS] = {}; u32 nChunks = 0; bool complete = false; };
 
 struct dy_ctx
 {
     int device = 0;
+    PendingSweep pending;
+    SweepTiming sweepTiming[2];
+    hipEvent_t evFetch = nullptr;
     Tuning tune;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
@@ -372,8 +381,10 @@ static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & r
 }
 
 // The bin masks of `reads` may still be in the making on the sweep stream: the main stream waits for them (device side, no host stall).
+static void sweepFlush(dy_ctx * ctx);
 static void waitForMasks(dy_ctx * ctx, dy_reads * reads)
 {
+    if (ctx->pending.reads == reads) sweepFlush(ctx);       // a deferred sweep of these reads: whatever is left of it runs now, on this stream
     if (reads->k1Pending) HIP_CHECK(hipStreamWaitEvent(ctx->stream, reads->evK1[1], 0));
 }
 // ... and once the main stream has been synchronised behind that wait, the sweep's duration can be read
@@ -386,6 +397,9 @@ static void collectSweepTime(dy_ctx * ctx, dy_reads * reads)
     HIP_CHECK(hipEventElapsedTime(&ms, reads->evK1[0], reads->evK1[1]));
     ctx->stats.ms_ibf = ms; reads->k1Pending = false;
 }
+
+static void fetchSync(dy_ctx * ctx);
+static void collectDeferredSweepTime(dy_ctx * ctx);
 
 // Work list (bin-major): (read,bin) items of the masks on `reads` -> ctx->itemRead / itemBin / binStart (+ the local sortedBins() rank).
 static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
@@ -421,7 +435,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (exact > 0x7FFFFFFFull) throw DyError(DY_EUNSUPPORTED, "more than 2^31 (read, bin) pairs in one batch: map fewer reads per batch");
             }
-            HIP_CHECK(hipStreamSynchronize(st));
+            fetchSync(ctx);
             nItems = *ctx->hostItems.as<u32>();
             collectSweepTime(ctx, reads);
             ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
@@ -457,8 +471,10 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
                            nWaves, nBins, ctx->binStart.as<u32>());
         hipLaunchKernelGGL(k_items_bin_rank, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->binStart.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
         ctx->devItemCount = ctx->waveOffsets.as<u32>() + nCells;
-        HIP_CHECK(hipMemcpyAsync(&nItems, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        ctx->hostItems.reserve(64);
+        HIP_CHECK(hipMemcpyAsync(ctx->hostItems.p, ctx->waveOffsets.as<u32>() + nCells, 4, hipMemcpyDeviceToHost, st));
+        fetchSync(ctx);
+        nItems = *ctx->hostItems.as<u32>();
         collectSweepTime(ctx, reads);
         ctx->itemRead.reserve((size_t)nItems * 4 + 64); ctx->itemBin.reserve((size_t)nItems * 2 + 64);
         if (nItems)
@@ -538,7 +554,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             }
             ctx->hostCounters.reserve(COUNTER_BYTES);
             HIP_CHECK(hipMemcpyAsync(ctx->hostCounters.p, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
+            fetchSync(ctx);
             memcpy(hostCounters, ctx->hostCounters.p, COUNTER_BYTES);
             memcpy(&poolTotal, hostCounters + COUNTER_POOL64, 8);
             if (!hostCounters[1]) break;
@@ -808,6 +824,7 @@ int dy_ctx_create(int device, dy_ctx ** out)
         for (auto & e : c->ev) HIP_CHECK(hipEventCreate(&e));
         for (auto & q : c->side) HIP_CHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&c->evFetch, hipEventDisableTiming));
         for (auto & e : c->evJoin) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         *out = c.release();
     });
@@ -822,6 +839,8 @@ void dy_ctx_free(dy_ctx * ctx)
     for (auto & e : ctx->ev) if (e) (void)hipEventDestroy(e);
     for (auto & q : ctx->side) if (q) (void)hipStreamDestroy(q);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    if (ctx->evFetch) (void)hipEventDestroy(ctx->evFetch);
+    for (auto & T : ctx->sweepTiming) for (auto & e : T.ev) if (e) (void)hipEventDestroy(e);
     for (auto & e : ctx->evJoin) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -849,7 +868,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
             {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255}, {"ibf_own_stream", &t.ibfOwnStream, 0, 1},
-            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1},
+            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1}, {"sweep_chunk", &t.sweepChunk, 1024, 2097151},
         };
         for (auto & k : keys)
             if (!strcmp(k.name, key))
@@ -1055,7 +1074,7 @@ int dy_ibf_get_info(const dy_ibf * f, dy_ibf_info * info)
     return DY_OK;
 }
 
-void dy_ibf_free(dy_ibf * f) { if (f) { (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->ibfStream); (void)hipStreamSynchronize(f->ctx->stream); delete f; } }
+void dy_ibf_free(dy_ibf * f) { if (f) { if (f->ctx->pending.f == f) { f->ctx->pending.f = nullptr; f->ctx->pending.reads = nullptr; } (void)hipSetDevice(f->ctx->device); (void)hipStreamSynchronize(f->ctx->ibfStream); (void)hipStreamSynchronize(f->ctx->stream); delete f; } }
 
 uint16_t dy_ibf_threshold(float error_rate, uint32_t kmer_size, uint16_t read_len)
 {
@@ -1136,9 +1155,157 @@ void dy_reads_free(dy_reads * r)
     (void)hipSetDevice(r->ctx->device);
     if (r->k1Pending) (void)hipEventSynchronize(r->evK1[1]);      // a sweep nobody waited for still writes the masks
     if (r->ctx->shBatch == r) r->ctx->shBatch = nullptr;
+    if (r->ctx->pending.reads == r) { (void)hipStreamSynchronize(r->ctx->stream); r->ctx->pending.reads = nullptr; r->ctx->pending.f = nullptr; }     // chunks already queued write its masks
     for (auto & e : r->evK1) if (e) (void)hipEventDestroy(e);
     if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); giveBuffer(r->ctx, r->orig); }
     delete r;
+}
+
+// The sweep of reads [first, first + count) of `reads` on stream sq (K1: whichBins of both strands, reference src/d_bloom_filter.h:161-224 through
+// src/d_mapper.h:350-358).  The kernels index a read by its wavefront, so a sub-range is the same launch on shifted offsets / masks.
+static void launchSweep(dy_ibf * f, dy_reads * reads, u32 threshold, u32 first, u32 count, hipStream_t sq)
+{
+            dy_ctx * ctx = f->ctx;
+            const u32 W = f->g.W;
+            const u64 * offs = reads->offs.as<u64>() + first;
+            u64 * masks = reads->masks.as<u64>() + (size_t)first * W;
+            const bool longReads = reads->maxLen >= 127 + f->g.kmerSize;
+            const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
+            u32 gShift = 0;
+            while ((1u << gShift) < W && gShift < 4) ++gShift;
+            const u32 G = 1u << gShift;
+            // LDS per wave of the two sweeps for W > 1 (see ibf_kernels.h)
+            const size_t hs = ((size_t)nKmax + 31) & ~(size_t)31;
+            const size_t lazyWave = (2 * hs + 128 + (size_t)nKmax * G + 33 * G) * 8;
+            const u32 listCap = 384;                            // surviving bits of a strand: one per k-mer of the read's own bin + ~0.5 false ones per k-mer
+            const size_t eagerWave = (hs + 128 + 17 * G + 1 + (listCap + 1) / 2) * 8;
+            u32 kernel = 3;
+            if (W > 1 && !ctx->tune.ibfNarrow && nKmax >= 1 && nKmax <= 255)
+            {
+                kernel = (u32)ctx->tune.ibfKernel;
+                if (kernel == 0) kernel = ibfExpectedFalseCandidates(f, nKmax, threshold) < 0.5 ? 1 : 2;
+                if ((kernel == 1 && lazyWave > 60 * 1024) || (kernel == 2 && eagerWave > 60 * 1024)) kernel = 3;
+            }
+            if (kernel == 1 || kernel == 2)
+            {
+                u32 slack = ibfSlack(f, nKmax, threshold);                      // (the fill estimate may use the stream: the timed region starts behind it)
+                // the lazy sweep gains from a slightly later first stop than the "false bins have died" point (256 bins / 16 GiB, 100 bp:
+                // slack 8 -> 4.32-4.42 ms, 9 -> 4.29, 10 -> 4.23-4.25, 11 -> 4.36 per 1 M reads): more of the own bin's carriers are at hand
+                if (kernel == 1 && !ctx->tune.ibfSlack) slack = std::min<u32>(slack + 2, (u32)threshold);
+                const size_t perWave = kernel == 1 ? lazyWave : eagerWave;
+                const u32 wavesPerBlock = perWave * 4 <= 32 * 1024 ? 4 : perWave * 2 <= 32 * 1024 ? 2 : 1;
+                const dim3 grid((count + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+                ctx->stats.ibf_kernel = kernel == 1 ? 4 : 5; ctx->stats.ibf_slack = slack;
+                if (kernel == 1)
+                    hipLaunchKernelGGL(k_ibf_query_lazy, grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), offs,
+                                       count, (u32)threshold, masks, gShift, nKmax, slack);
+                else
+                    hipLaunchKernelGGL(k_ibf_query_eager2, grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), offs,
+                                       count, (u32)threshold, masks, gShift, nKmax, listCap);
+            }
+            else if (W == 1 || ctx->tune.ibfNarrow)
+            {
+                const u32 wavesPerBlock = 4;
+                const dim3 grid((count + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+                if (W == 1 && nKmax > 64 && nKmax <= 127 && !ctx->tune.ibfFullTail)
+                {
+                    const u32 slack = ibfSlack(f, nKmax, threshold);
+                    // tail k-mers requested with the first round: worth their look-ups only where a strand is expected to leave the first
+                    // round with a weak bin (a bin that reaches threshold - tail hits among the first 64 k-mers by chance): 4 at the
+                    // fill of a 1 GiB filter (0.97 weak bins per strand), none at 16 GiB
+                    u32 tailPre = 0;
+                    {
+                        const u32 n0 = std::min<u32>(std::min<u32>(nKmax, 64u), std::max<u32>(threshold, nKmax - std::min<u32>(threshold, nKmax) + slack));
+                        const u32 tail = nKmax - n0;
+                        if (tail && threshold > tail && ibfExpectedFalseCandidates(f, n0, threshold - tail) >= 0.5) tailPre = 4;
+                    }
+                        ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack;
+                    hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), offs,
+                                       count, (u32)threshold, masks, slack, tailPre);
+                }
+                else if (!longReads)
+                {
+                    ctx->stats.ibf_kernel = 2;
+                    hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), offs,
+                                       count, (u32)threshold, masks);
+                }
+                else
+                {
+                    ctx->stats.ibf_kernel = 3;
+                    hipLaunchKernelGGL(k_ibf_query<14>, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), offs,
+                                       count, (u32)threshold, masks);
+                }
+            }
+            else
+            {   // G = lanes per k-mer; LDS per wave = 64 hashes + the hash-0 words of as many k-mers as fit in ~19 KB
+                const u32 nK = nKmax;
+                ctx->stats.ibf_kernel = 6;
+                const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
+                // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
+                const u32 ldsBudget = (u32)ctx->tune.ibfLdsKb * 1024;
+                // sparse verification pays when false candidates are expected in numbers, i.e. at thresholds far below the k-mer count
+                const u32 sparseCap = (nK < 256 && nK <= hashSlots && 4u * threshold <= nK && !ctx->tune.ibfDense) ? 1024 : 0;
+                const u32 fixedWords = hashSlots + (sparseCap ? 16 + 128 + sparseCap / 4 : 0);
+                const u32 cacheKmers = ldsBudget > fixedWords * 8 ? std::min<u32>(nK, (u32)((ldsBudget - fixedWords * 8) / (G * 8))) : 0;
+                const size_t perWave = ((size_t)fixedWords + (size_t)cacheKmers * G) * 8;
+                const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
+                const dim3 grid((count + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
+#define DY_LAUNCH_WIDE(NPV, SP) hipLaunchKernelGGL((k_ibf_query_wide<NPV, SP>), grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, \
+                                   reads->seqs.as<u8>(), offs, count, (u32)threshold, masks, gShift, cacheKmers, hashSlots, sparseCap)
+                if (nK <= 127) { if (sparseCap) DY_LAUNCH_WIDE(7, true); else DY_LAUNCH_WIDE(7, false); }
+                else if (nK <= 255) { if (sparseCap) DY_LAUNCH_WIDE(8, true); else DY_LAUNCH_WIDE(8, false); }
+                else DY_LAUNCH_WIDE(14, false);
+#undef DY_LAUNCH_WIDE
+            }
+            HIP_CHECK(hipGetLastError());
+}
+
+// ---- deferred sweep: K1 of the batch mapped NEXT, cut into chunks that are queued in front of the host's waits ----------------------
+// A sweep holds every wave slot of the chip, so a second stream cannot run beside it: what CAN be overlapped are the waits of
+// the host — for a count it has to read (work-list size, pool counter, the rows of an exchange) or for a peer.  A chunk of the pending
+// sweep queued right before such a wait keeps the device busy while the host is away; the kernels the host queues afterwards run behind it.
+static void sweepChunk(dy_ctx * ctx, u32 maxReads)
+{
+    PendingSweep & P = ctx->pending;
+    if (!P.reads || P.next >= P.reads->n) return;
+    const u32 count = std::min<u32>(maxReads ? maxReads : (u32)ctx->tune.sweepChunk, P.reads->n - P.next);
+    SweepTiming & T = ctx->sweepTiming[P.slot];
+    const bool timed = T.nChunks < SweepTiming::MAX_CHUNKS;
+    if (timed) HIP_CHECK(hipEventRecord(T.ev[2 * T.nChunks], ctx->stream));
+    launchSweep(P.f, P.reads, P.threshold, P.next, count, ctx->stream);
+    if (timed) { HIP_CHECK(hipEventRecord(T.ev[2 * T.nChunks + 1], ctx->stream)); ++T.nChunks; }
+    P.next += count;
+}
+static void sweepFlush(dy_ctx * ctx)
+{
+    PendingSweep & P = ctx->pending;
+    if (P.reads && P.next < P.reads->n) sweepChunk(ctx, P.reads->n - P.next);
+    if (P.reads) ctx->sweepTiming[P.slot].complete = true;
+    P.reads = nullptr; P.f = nullptr;
+}
+// device time of a completed deferred sweep (its chunks' events), once everything queued has run
+static void collectDeferredSweepTime(dy_ctx * ctx)
+{
+    for (SweepTiming & T : ctx->sweepTiming)
+    {
+        if (!T.complete || !T.nChunks) continue;
+        if (hipEventQuery(T.ev[2 * T.nChunks - 1]) != hipSuccess) continue;
+        double total = 0;
+        for (u32 c = 0; c < T.nChunks; ++c) { float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, T.ev[2 * c], T.ev[2 * c + 1])); total += ms; }
+        ctx->stats.ms_ibf = total;
+        T.complete = false; T.nChunks = 0;
+    }
+}
+// the host is about to wait for what it has just queued on the stream (a small fetch): a chunk of the pending sweep goes behind it first
+static void fetchSync(dy_ctx * ctx)
+{
+    if (ctx->pending.reads && ctx->pending.next < ctx->pending.reads->n)
+    {
+        HIP_CHECK(hipEventRecord(ctx->evFetch, ctx->stream));
+        sweepChunk(ctx, 0);
+        HIP_CHECK(hipEventSynchronize(ctx->evFetch));
+    }
+    else HIP_CHECK(hipStreamSynchronize(ctx->stream));
 }
 
 int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bin_masks_host)
@@ -1168,98 +1335,9 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
         }
         if (reads->n)
         {
+            if (ctx->pending.reads == reads) { ctx->pending.reads = nullptr; ctx->pending.f = nullptr; }      // superseded
             HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
-            const bool longReads = reads->maxLen >= 127 + f->g.kmerSize;
-            const u32 nKmax = reads->maxLen >= f->g.kmerSize ? reads->maxLen - f->g.kmerSize + 1 : 0;
-            u32 gShift = 0;
-            while ((1u << gShift) < W && gShift < 4) ++gShift;
-            const u32 G = 1u << gShift;
-            // LDS per wave of the two sweeps for W > 1 (see ibf_kernels.h)
-            const size_t hs = ((size_t)nKmax + 31) & ~(size_t)31;
-            const size_t lazyWave = (2 * hs + 128 + (size_t)nKmax * G + 33 * G) * 8;
-            const u32 listCap = 384;                            // surviving bits of a strand: one per k-mer of the read's own bin + ~0.5 false ones per k-mer
-            const size_t eagerWave = (hs + 128 + 17 * G + 1 + (listCap + 1) / 2) * 8;
-            u32 kernel = 3;
-            if (W > 1 && !ctx->tune.ibfNarrow && nKmax >= 1 && nKmax <= 255)
-            {
-                kernel = (u32)ctx->tune.ibfKernel;
-                if (kernel == 0) kernel = ibfExpectedFalseCandidates(f, nKmax, threshold) < 0.5 ? 1 : 2;
-                if ((kernel == 1 && lazyWave > 60 * 1024) || (kernel == 2 && eagerWave > 60 * 1024)) kernel = 3;
-            }
-            if (kernel == 1 || kernel == 2)
-            {
-                u32 slack = ibfSlack(f, nKmax, threshold);                      // (the fill estimate may use the stream: the timed region starts behind it)
-                // the lazy sweep gains from a slightly later first stop than the "false bins have died" point (256 bins / 16 GiB, 100 bp:
-                // slack 8 -> 4.32-4.42 ms, 9 -> 4.29, 10 -> 4.23-4.25, 11 -> 4.36 per 1 M reads): more of the own bin's carriers are at hand
-                if (kernel == 1 && !ctx->tune.ibfSlack) slack = std::min<u32>(slack + 2, (u32)threshold);
-                HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
-                const size_t perWave = kernel == 1 ? lazyWave : eagerWave;
-                const u32 wavesPerBlock = perWave * 4 <= 32 * 1024 ? 4 : perWave * 2 <= 32 * 1024 ? 2 : 1;
-                const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-                ctx->stats.ibf_kernel = kernel == 1 ? 4 : 5; ctx->stats.ibf_slack = slack;
-                if (kernel == 1)
-                    hipLaunchKernelGGL(k_ibf_query_lazy, grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, slack);
-                else
-                    hipLaunchKernelGGL(k_ibf_query_eager2, grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, nKmax, listCap);
-            }
-            else if (W == 1 || ctx->tune.ibfNarrow)
-            {
-                const u32 wavesPerBlock = 4;
-                const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-                if (W == 1 && nKmax > 64 && nKmax <= 127 && !ctx->tune.ibfFullTail)
-                {
-                    const u32 slack = ibfSlack(f, nKmax, threshold);
-                    // tail k-mers requested with the first round: worth their look-ups only where a strand is expected to leave the first
-                    // round with a weak bin (a bin that reaches threshold - tail hits among the first 64 k-mers by chance): 4 at the
-                    // fill of a 1 GiB filter (0.97 weak bins per strand), none at 16 GiB
-                    u32 tailPre = 0;
-                    {
-                        const u32 n0 = std::min<u32>(std::min<u32>(nKmax, 64u), std::max<u32>(threshold, nKmax - std::min<u32>(threshold, nKmax) + slack));
-                        const u32 tail = nKmax - n0;
-                        if (tail && threshold > tail && ibfExpectedFalseCandidates(f, n0, threshold - tail) >= 0.5) tailPre = 4;
-                    }
-                    HIP_CHECK(hipEventRecord(reads->evK1[0], sq));
-                    ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack;
-                    hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>(), slack, tailPre);
-                }
-                else if (!longReads)
-                {
-                    ctx->stats.ibf_kernel = 2;
-                    hipLaunchKernelGGL(k_ibf_query<7>, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>());
-                }
-                else
-                {
-                    ctx->stats.ibf_kernel = 3;
-                    hipLaunchKernelGGL(k_ibf_query<14>, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), reads->offs.as<u64>(),
-                                       reads->n, (u32)threshold, reads->masks.as<u64>());
-                }
-            }
-            else
-            {   // G = lanes per k-mer; LDS per wave = 64 hashes + the hash-0 words of as many k-mers as fit in ~19 KB
-                const u32 nK = nKmax;
-                ctx->stats.ibf_kernel = 6;
-                const u32 hashSlots = nK <= 512 ? ((nK + 63) & ~63u) : 128;                   // all hashes of a strand, or a window
-                // measured on the 1024-bin geometry: 19 KB per wave 41.3 ms, 12 KB 32.1 ms, 8 KB 34.4 ms (LDS limits the waves per CU; words not cached are gathered again)
-                const u32 ldsBudget = (u32)ctx->tune.ibfLdsKb * 1024;
-                // sparse verification pays when false candidates are expected in numbers, i.e. at thresholds far below the k-mer count
-                const u32 sparseCap = (nK < 256 && nK <= hashSlots && 4u * threshold <= nK && !ctx->tune.ibfDense) ? 1024 : 0;
-                const u32 fixedWords = hashSlots + (sparseCap ? 16 + 128 + sparseCap / 4 : 0);
-                const u32 cacheKmers = ldsBudget > fixedWords * 8 ? std::min<u32>(nK, (u32)((ldsBudget - fixedWords * 8) / (G * 8))) : 0;
-                const size_t perWave = ((size_t)fixedWords + (size_t)cacheKmers * G) * 8;
-                const u32 wavesPerBlock = perWave > 8 * 1024 ? 2 : 4;
-                const dim3 grid((reads->n + wavesPerBlock - 1) / wavesPerBlock), block(64 * wavesPerBlock);
-#define DY_LAUNCH_WIDE(NPV, SP) hipLaunchKernelGGL((k_ibf_query_wide<NPV, SP>), grid, block, perWave * wavesPerBlock, sq, f->words.as<u64>(), f->g, \
-                                   reads->seqs.as<u8>(), reads->offs.as<u64>(), reads->n, (u32)threshold, reads->masks.as<u64>(), gShift, cacheKmers, hashSlots, sparseCap)
-                if (nK <= 127) { if (sparseCap) DY_LAUNCH_WIDE(7, true); else DY_LAUNCH_WIDE(7, false); }
-                else if (nK <= 255) { if (sparseCap) DY_LAUNCH_WIDE(8, true); else DY_LAUNCH_WIDE(8, false); }
-                else DY_LAUNCH_WIDE(14, false);
-#undef DY_LAUNCH_WIDE
-            }
-            HIP_CHECK(hipGetLastError());
+            launchSweep(f, reads, (u32)threshold, 0, reads->n, sq);
             HIP_CHECK(hipEventRecord(reads->evK1[1], sq));
         }
         if (bin_masks_host)
@@ -1270,6 +1348,38 @@ int dy_ibf_query(dy_ibf * f, dy_reads * reads, uint16_t threshold, uint64_t * bi
             reads->k1Pending = false;
         }
         else if (reads->n) reads->k1Pending = true;
+    });
+}
+
+
+int dy_ibf_query_deferred(dy_ibf * f, dy_reads * reads, uint16_t threshold)
+{
+    return guarded([&] {
+        if (!f || !reads) throw DyError(DY_EINVAL, "dy_ibf_query_deferred: NULL argument");
+        if (f->ctx != reads->ctx) throw DyError(DY_EINVAL, "filter and reads belong to different contexts");
+        dy_ctx * ctx = f->ctx;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (ctx->pending.reads && ctx->pending.reads != reads) sweepFlush(ctx);        // one pending sweep per context
+        if (reads->k1Pending) { HIP_CHECK(hipStreamWaitEvent(ctx->stream, reads->evK1[1], 0)); reads->k1Pending = false; }   // an earlier sweep on the other stream writes the same masks
+        const u32 W = f->g.W;
+        if (reads->recycle && !reads->masks.p) takeBuffer(ctx, reads->masks, (size_t)reads->n * W * 8 + 8);
+        else reads->masks.reserve((size_t)reads->n * W * 8 + 8);
+        reads->maskW = W; reads->maskBins = f->g.nBins;
+        PendingSweep & P = ctx->pending;
+        P.f = f; P.reads = reads; P.threshold = threshold; P.next = 0; P.slot ^= 1u;
+        SweepTiming & T = ctx->sweepTiming[P.slot];
+        T.nChunks = 0; T.complete = false;
+        for (auto & e : T.ev) if (!e) HIP_CHECK(hipEventCreate(&e));
+        (void)ibfFill(f);                                                                // the sampled fill (a synchronising estimate) is taken now, not inside a chunk
+    });
+}
+
+int dy_ctx_background_chunk(dy_ctx * ctx, uint32_t max_reads)
+{
+    return guarded([&] {
+        if (!ctx) throw DyError(DY_EINVAL, "ctx is NULL");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        sweepChunk(ctx, max_reads);
     });
 }
 
@@ -1520,10 +1630,11 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
 
         res->readLens = reads->lens;       // for the host-side MAPQ (shared, not copied)
-        u32 badGroup = 0;
-        HIP_CHECK(hipMemcpyAsync(&badGroup, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        if (badGroup) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
+        ctx->hostStatus.reserve(64);
+        HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.p, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, st));
+        fetchSync(ctx);
+        if (*ctx->hostStatus.as<u32>()) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
+        collectDeferredSweepTime(ctx);
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.ms_search = ms;
@@ -1793,7 +1904,7 @@ int dy_map_bins(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_p
         if (paired) HIP_CHECK(hipMemcpyAsync(status, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, ctx->stream));      // k_group_matches ran (pairing stages)
         if (ctx->shBatch == reads) HIP_CHECK(hipMemcpyAsync(status + 1, ctx->shFlags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         if (bin_loads) HIP_CHECK(hipMemcpyAsync(status + 16, ctx->binStart.p, (size_t)(nBins + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (paired || ctx->shBatch == reads || bin_loads) HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (paired || ctx->shBatch == reads || bin_loads) fetchSync(ctx);
         if (status[1]) throw DyError(DY_EINVAL, "dy_shard_c1_unpack: the received segments are inconsistent with their headers");
         if (status[0]) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
         if (bin_loads) for (u32 b = 0; b < nBins; ++b) bin_loads[b] = status[16 + b + 1] - status[16 + b];
@@ -1914,9 +2025,12 @@ int dy_shard_finalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, cons
         HIP_CHECK(hipEventRecord(ctx->ev[6], st));
         res->readLens = reads->lens;
         u32 flags[COUNTER_BYTES / 4];
-        HIP_CHECK(hipMemcpyAsync(flags, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        ctx->hostCounters.reserve(COUNTER_BYTES);
+        HIP_CHECK(hipMemcpyAsync(ctx->hostCounters.p, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
+        fetchSync(ctx);
+        memcpy(flags, ctx->hostCounters.p, COUNTER_BYTES);
         collectSweepTime(ctx, reads);
+        collectDeferredSweepTime(ctx);
         if (flags[7]) throw DyError(DY_EINVAL, "dy_shard_finalize: a raw match or pairing record names a read / bin outside the batch's selection");
         if (flags[COUNTER_BAD_GROUP]) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
         float ms;

@@ -13,8 +13,9 @@ same unit: one child Mapper per bin, merged per read by copyMatches / finalizeMa
 Everything is queued on the context's HIP stream, which is torch's current stream while a batch is mapped (torch.cuda.ExternalStream):
 RCCL's own stream is ordered against it by events, so the only host synchronisations of a batch are the two fetches of the counts (the
 sizes of an all-to-all(v) are host arguments), those inside dy_map_bins and the one that ends dy_shard_finalize.  With `prefetch`, the
-IBF sweep of the NEXT batch is queued on the context's second stream right after C1 is packed, so the exchanges and their latencies run
-under it.
+IBF sweep of the NEXT batch is registered as soon as C1 is packed (dy_ibf_query_deferred): a chunk of it is queued in front of every
+one of those waits, so the device sweeps while the host reads a count or waits for a peer (a whole sweep on a second stream would not
+do: it holds every wave slot and everything else runs in its tail).
 """
 import contextlib
 import os
@@ -77,10 +78,11 @@ def device_view(ptr, nbytes, device):
     return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
 
 
-def exchange_rows(dist, rows, row_bytes, world, stream=None, pinned=None):
+def exchange_rows(dist, rows, row_bytes, world, stream=None, pinned=None, before_wait=None):
     """rows: uint8 tensor of world x row_bytes, row d = what this rank has for rank d.  Returns (the rows as sent, the rows received) as
     host uint8 arrays of shape (world, row_bytes) — after ONE synchronisation of `stream` (nccl) / of the staging copies (gloo).
-    pinned: a reusable pinned uint8 tensor of at least 2 x rows.numel() bytes (allocating one costs milliseconds)."""
+    pinned: a reusable pinned uint8 tensor of at least 2 x rows.numel() bytes (allocating one costs milliseconds).
+    before_wait: called after the fetch is queued and before the host waits for it (nccl only)."""
     if dist is None:                                               # one rank, no process group: what is sent is what is received
         mine = rows.cpu().numpy().reshape(world, row_bytes)
         return mine, mine
@@ -90,7 +92,13 @@ def exchange_rows(dist, rows, row_bytes, world, stream=None, pinned=None):
         both = pinned[: 2 * rows.numel()] if pinned is not None else torch.empty(2 * rows.numel(), dtype=torch.uint8, pin_memory=True)
         both[: rows.numel()].copy_(rows, non_blocking=True)
         both[rows.numel():].copy_(got, non_blocking=True)
-        (stream or torch.cuda.current_stream()).synchronize()
+        if before_wait is not None:                                # something useful for the device to do while the host is away (a chunk of the next sweep)
+            ev = torch.cuda.Event()
+            ev.record(stream or torch.cuda.current_stream())
+            before_wait()
+            ev.synchronize()
+        else:
+            (stream or torch.cuda.current_stream()).synchronize()
         host = both.numpy()
         return host[: rows.numel()].reshape(world, row_bytes).copy(), host[rows.numel():].reshape(world, row_bytes).copy()
     mine = rows.cpu().contiguous()
@@ -161,8 +169,6 @@ class ShardedMapper:
         self.row2 = dy.shard_c2_row_bytes(n_bins)
         self.stream = torch.cuda.ExternalStream(ctx.stream()) if device != "cpu" else None
         self.prefetch = bool(prefetch)
-        if self.prefetch:
-            ctx.set_tuning("ibf_own_stream", 1)
         with self._on_stream():
             self.hdr = torch.zeros(world * dy.SEG_HEADER_BYTES, dtype=torch.uint8, device=device)
             self.rows = torch.zeros(world * self.row2, dtype=torch.uint8, device=device)
@@ -191,10 +197,12 @@ class ShardedMapper:
             self._swept = None
             # ---- C1: reads -> owners of their selected bins
             send_ptr = dy.shard_c1_pack(ctx, reads, self.owner_masks, paired, self.hdr.data_ptr())
+            chunk = None
             if self.prefetch and next_reads is not None and not (paired and next_reads is reads):
-                self.ibf.query(next_reads, threshold, want_masks=False)                  # K1 of the next batch, on the sweep stream, behind the pack
+                self.ibf.query_deferred(next_reads, threshold)                           # K1 of the next batch: chunks of it go in front of every wait of the host
                 self._swept = next_reads
-            mine, theirs = exchange_rows(self.dist, self.hdr, dy.SEG_HEADER_BYTES, world, self.stream, self.pinned)
+                chunk = ctx.background_chunk
+            mine, theirs = exchange_rows(self.dist, self.hdr, dy.SEG_HEADER_BYTES, world, self.stream, self.pinned, chunk)
             h_out = np.ascontiguousarray(mine).view(dy.SEG_HEADER_DTYPE).reshape(world)
             h_in = np.ascontiguousarray(theirs).view(dy.SEG_HEADER_DTYPE).reshape(world)
             send = device_view(send_ptr, int(h_out["bytes"].sum()), dev)
@@ -204,7 +212,7 @@ class ShardedMapper:
             # ---- C2: raw matches (+ pairing records) -> the read's home rank
             send_ptr = dy.shard_c2_pack(ctx, self.rows.data_ptr())
             sub.close()
-            mine, theirs = exchange_rows(self.dist, self.rows, self.row2, world, self.stream, self.pinned)
+            mine, theirs = exchange_rows(self.dist, self.rows, self.row2, world, self.stream, self.pinned, chunk)
             r_out = np.ascontiguousarray(mine[:, : dy.SEG_HEADER_BYTES]).view(dy.SEG_HEADER_DTYPE).reshape(world)
             r_in = np.ascontiguousarray(theirs[:, : dy.SEG_HEADER_BYTES]).view(dy.SEG_HEADER_DTYPE).reshape(world)
             send2 = device_view(send_ptr, int(r_out["bytes"].sum()), dev)

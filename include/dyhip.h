@@ -57,7 +57,7 @@ void       *dy_ctx_stream(dy_ctx *ctx);
  * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next
  * batch's sweep can be queued before the current batch is mapped), dp_small_blocks (64-65536, 4096) and dp_align_blocks (64-65536, 8192: grids of the
  * thread-level aggregation / alignment kernels), items_sorted (0-1, 1: work list as (bin, read) pairs + stable radix sort; 0 = bin-major
- * count matrix), pool_cap (initial raw-match
+ * count matrix), sweep_chunk (1024-2097151, 16384: reads per chunk of a deferred sweep), pool_cap (initial raw-match
  * pool capacity, 0 = automatic; the pool grows and the extension is re-run on overflow).  Stands where the reference has
  * compile-time template switches (reference src/mapper.h:128-206 MapperConfig / Limits).  Unknown key or value: DY_EINVAL. */
 int         dy_ctx_set_tuning(dy_ctx *ctx, const char *key, uint64_t value);
@@ -113,6 +113,17 @@ void dy_reads_free(dy_reads *r);
  * bin_masks_host (n_reads*W words, may be NULL) receives a copy; the masks also stay on the device for dy_map_reads.
  * threshold 0 reproduces the reference's "every read to every bin" (src/d_mapper.h:320-333) without the duplicate pass. */
 int  dy_ibf_query(dy_ibf *f, dy_reads *reads, uint16_t threshold, uint64_t *bin_masks_host);
+
+/* The same sweep, DEFERRED: for the batch a caller maps NEXT.  A sweep holds every wave slot of the device, so nothing can run beside it;
+ * what it can hide are the host's waits inside the mapping of the CURRENT batch (for a count the host must read, for a peer rank).
+ * The library queues the pending sweep chunk by chunk (tuning key sweep_chunk, reads per chunk, default 16384) in front of each of its
+ * own waits, and whatever is left when the masks are first needed (dy_map_reads, dy_shard_c1_pack, ...).  One pending sweep per
+ * context; the caller must not need the previous masks of `reads` any more.  Stands where the reference lets a prefetch thread load
+ * the next reads while the current batch is mapped (src/file_prefetched.h:140; src/d_mapper.h:868-887 loop). */
+int  dy_ibf_query_deferred(dy_ibf *f, dy_reads *reads, uint16_t threshold);
+/* Queues one chunk of the pending deferred sweep (max_reads reads, 0 = the default chunk) on the context's stream: for a caller that
+ * is about to wait for an event it recorded on dy_ctx_stream() (the fetch of an exchange's counts).  No-op without a pending sweep. */
+int  dy_ctx_background_chunk(dy_ctx *ctx, uint32_t max_reads);
 
 /* `-ft none`: every read goes to every bin (reference src/d_mapper.h:399-405) — sets the masks dy_ibf_query would set.  dy_map_reads does
  * this by itself when use_filter = 0; the bins-sharded sequence (dy_shard_c1_pack ...) needs the masks on the reads first. */

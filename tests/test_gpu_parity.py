@@ -320,6 +320,52 @@ def test_map_matches_oracle_on_gold_data(dy, ctx, ob, small_filter, strata):
     oidx.close(); oibf.close()
 
 
+@pytest.mark.parametrize("chunk", [1024, 16384])
+def test_deferred_sweep_gives_the_same_masks_and_results(dy, ob, small_filter, chunk):
+    """dy_ibf_query_deferred: the sweep of the batch mapped next is queued chunk by chunk in front of the host's waits of the current
+    mapping, the rest when its masks are first needed.  Two batches alternate three times; every result equals the plain sequence
+    (sweep, then map) and the oracle.  1024 reads per chunk: more chunks than the timing slots hold, and the sweep finishes early."""
+    c = dy.Context(0)
+    try:
+        c.set_tuning("sweep_chunk", chunk)
+        _, codes, offs = read_fasta_codes(READS_FA)
+        er = np.float32(3 / 100.0)
+        cutA, cutB = 3500, 6400
+        a = (codes[: int(offs[cutA])], offs[: cutA + 1].copy())
+        b = (codes[int(offs[cutA]): int(offs[cutB])], (offs[cutA: cutB + 1] - offs[cutA]).astype(np.uint64))
+        idx = dy.Index(c, GOLD_INDEX, 64)
+        ibf = dy.Ibf.load(c, small_filter)
+        thr = dy.threshold(er, 19, 100)
+        params = dy.default_params(error_rate=er)
+        ra, rb = dy.Reads(c, *a), dy.Reads(c, *b)
+        want = {}
+        for name, r in (("a", ra), ("b", rb)):
+            masks = ibf.query(r, thr)
+            res = dy.map_reads(c, idx, r, params)
+            want[name] = (masks, res.reads(), res.matches(), res.cigars()); res.close()
+        ibf.query(ra, thr, want_masks=False)
+        for it in range(3):
+            for cur, nxt, name in ((ra, rb, "a"), (rb, ra, "b")):
+                ibf.query_deferred(nxt, thr)                     # registered before the current batch is mapped: its chunks ride on this mapping's waits
+                res = dy.map_reads(c, idx, cur, params)
+                got = (res.reads(), res.matches(), res.cigars()); res.close()
+                assert_results_equal(got, want[name][1:])
+        assert c.stats()["ms_ibf"] > 0
+        # a deferred sweep whose masks are read back directly, and one that is superseded by a plain sweep
+        ibf.query_deferred(rb, thr)
+        assert np.array_equal(ibf.query(rb, thr), want["b"][0])
+        ibf.query_deferred(ra, thr)
+        res = dy.map_reads(c, idx, ra, params)                   # needs the masks at once: the whole sweep is flushed in front of it
+        assert_results_equal((res.reads(), res.matches(), res.cigars()), want["a"][1:]); res.close()
+        oidx = ob.OracleIndex(GOLD_INDEX, 64); oibf = ob.OracleIbf(small_filter)
+        o = ob.map_batch(oidx, oibf, a[0], a[1], er)
+        assert_results_equal(want["a"][1:], o[:3])
+        oidx.close(); oibf.close()
+        ra.close(); rb.close(); ibf.close(); idx.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("tuning", [{"sparse_sa": 1}, {"prefix_q": 0}, {"no_isa": 1}, {"prefix_q": 6}, {"finalize_block_min": 3, "finalize_no_keys": 1},
                                     {"ibf_full_tail": 1}, {"items_sorted": 0}])
 def test_map_without_the_device_only_tables(dy, ob, small_filter, tuning):
