@@ -1219,7 +1219,7 @@ static void launchSweep(dy_ibf * f, dy_reads * reads, u32 threshold, u32 first, 
                         const u32 tail = nKmax - n0;
                         if (tail && threshold > tail && ibfExpectedFalseCandidates(f, n0, threshold - tail) >= 0.5) tailPre = 4;
                     }
-                        ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack;
+                        ctx->stats.ibf_kernel = 1; ctx->stats.ibf_slack = slack; ctx->stats.ibf_tail_pre = tailPre;
                     hipLaunchKernelGGL(k_ibf_query_two, grid, block, 0, sq, f->words.as<u64>(), f->g, reads->seqs.as<u8>(), offs,
                                        count, (u32)threshold, masks, slack, tailPre);
                 }

@@ -220,6 +220,8 @@ typedef struct {
     uint32_t ibf_kernel;     /* sweep the last dy_ibf_query ran: 1 k_ibf_query_two, 2 k_ibf_query<7>, 3 k_ibf_query<14>, 4 k_ibf_query_lazy,
                                 5 k_ibf_query_eager2, 6 k_ibf_query_wide (0 = none yet) */
     uint32_t ibf_slack;      /* first check of that sweep at nK - threshold + slack k-mers (derived from the sampled filter fill) */
+    uint32_t ibf_tail_pre;   /* k_ibf_query_two: tail k-mers requested with the first round (4 where the filter's fill makes weak bins the rule, else 0) */
+    uint32_t reserved;
 } dy_map_stats;
 int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
 

@@ -4,13 +4,15 @@ on the same seeded inputs, every field of every read.  The inputs are the bench'
   config2   64 bins x 4 Mbp,  1 GiB IBF,  1 M x 100 bp SE, e=3     full size: masks, results, item / raw-match counts
   config3  256 bins x 4 Mbp, 16 GiB IBF,  250 k x 100 bp SE, e=3   real filter size (W = 4), all 256 FM indices resident
   config4  256 bins, 16 GiB IBF, 100 k pairs 2 x 100 bp, e=3       pairing + rescue (the oracle's PE half is parity-unpinned: no PE gold exists)
-  config5 1024 bins x 4 Mbp, 64 GiB IBF, 150 bp, e=5 (threshold 7) K1 masks on a read sample against the oracle running on a host copy of
-                                                                   the device-resident filter + the own-bin property on the whole batch;
-                                                                   full results at L=150 / e=5 (8 seeds of 18 + 6-base tail) on the 64-bin index
+  config5 1024 bins x 4 Mbp, 64 GiB IBF, 150 bp, e=5 (threshold 7) all 1024 FM indices resident: K1 masks and every result field of 200 k reads
+                                                                   against the oracle running on a host copy of the device-resident filter,
+                                                                   the own-bin property on the whole 1 M batch
+  northstar 64 bins, 16 GiB IBF, one 2 M batch of 100 bp SE, e=3   the target sentence's geometry (the 10 M reads are 5 such batches)
+  256 bins sharded over two ranks (SE and PE)                      the partitioning of configs[2] / [3] at their bin count
 
 A batch of 10 M / 50 M reads is that many independent repetitions of these steps (reads never interact outside a pair), so the
 per-batch comparisons are the parity statement for the full configurations; the multi-GPU partitioning of the same work is covered
-by test_bin_sharded_two_ranks_equal_single_gpu.  Index directories are cached under the bench's work dir and reused by bench.py.
+by test_bins_sharded_two_ranks_at_256_bins here and test_bin_sharded_*_two_ranks_equal_single_gpu in test_gpu_parity.py.  Index directories are cached under the bench's work dir and reused by bench.py.
 """
 import os
 import sys
@@ -257,44 +259,131 @@ def test_config4_geometry_paired_end(dy, ob, geometry256):
     assert dev[0]["paired"].mean() > 0.9 and (dev[0]["cigar_len"] > 1).sum() > 100
 
 
-# ------------------------------------------------------------------------------------------------- configs[4] geometry: K1 at 1024 bins / 64 GiB
-def test_config5_geometry_ibf_sweep(dy, ob):
+# ------------------------------------------------------------------------------------------------- configs[4] geometry: 1024 bins / 64 GiB, the whole path
+def test_config5_geometry_full_path(dy, ob):
+    """BASELINE configs[4] on one GPU: 1024 bins x 4 Mbp with all FM indices resident (q = 11 q-mer table, u16 work items, radix-sorted
+    work list), the real 64 GiB filter (W = 16, k_ibf_query_eager2), 150 bp reads at -e 5 (threshold 7; 8 seeds of 18 + 6-base tail, the
+    16-lane alignment of wide bands).  K1 masks, every result field, items and raw matches of 200 k reads equal the oracle's; the
+    own-bin property holds on the whole 1 M batch."""
     from dream_yara_amd import synth
-    import bench
-    wl = bench.WORKLOADS["config5"]
-    t0 = time.time()
-    genomes = [synth.make_genome(b, wl["glen"]) for b in range(wl["bins"])]
-    _log("config5: 1024 genomes in %.1f s" % (time.time() - t0))
+    wl, genomes, idx_dir = _inputs("config5")
     ctx = dy.Context(0)
     try:
         ibf = _device_filter(dy, ctx, wl, genomes)
         info = ibf.info()
         assert info["words_per_pos"] == 16 and info["n_bits"] == (64 << 33) + 256
+        t0 = time.time()
+        index = dy.Index(ctx, idx_dir, wl["bins"])
+        _log("config5: 1024 FM indices uploaded in %.1f s" % (time.time() - t0))
         N = 1_000_000
         codes, offs, truth = synth.simulate_reads(genomes, N, 150, seed=0x5EED0005)
+        del genomes
         er = np.float32(0.05)
         thr = dy.threshold(er, wl["k"], 150)
         assert thr == 7
         reads = dy.Reads(ctx, codes, offs)
         d_masks = ibf.query(reads, thr)
+        assert ctx.stats()["ibf_kernel"] == 5                        # k_ibf_query_eager2
         reads.close()
         # property over the whole batch: a read with at most 7 errors keeps >= 7 error-free 18-mers, so its own bin is selected
         own = (d_masks[np.arange(N), truth["bin"] // 64] >> (truth["bin"] % 64).astype(np.uint64)) & np.uint64(1)
         assert own.mean() > 0.9999, own.mean()
-        # a second, smaller sweep gives the same words for the same reads (no dependence on batch geometry)
-        S = 30_000
-        reads = dy.Reads(ctx, codes[: int(offs[S])], offs[: S + 1])
+        # the whole path on the first 200 k reads (a smaller batch gives the same mask words: no dependence on batch geometry)
+        S = 200_000
+        c, o_ = codes[: int(offs[S])], offs[: S + 1]
+        reads = dy.Reads(ctx, c, o_)
         assert np.array_equal(ibf.query(reads, thr), d_masks[:S])
-        reads.close()
-        # exact: the oracle on a host copy of the device-resident 64 GiB filter, on a sample of the batch
+        res = dy.map_reads(ctx, index, reads, dy.default_params(error_rate=er))
+        dev = (res.reads(), res.matches(), res.cigars()); st = ctx.stats()
+        res.close(); reads.close(); index.close()
         oibf = _oracle_filter(ob, ibf)
         ibf.close()
         t0 = time.time()
-        o_masks = oibf.query(codes[: int(offs[S])], offs[: S + 1], thr, threads=THREADS)
-        _log("config5: oracle K1 on %d reads in %.1f s" % (S, time.time() - t0))
-        oibf.close()
+        o_masks = oibf.query(c, o_, thr, threads=THREADS)
         assert np.array_equal(d_masks[:S], o_masks), "K1 masks differ at %d reads" % int((d_masks[:S] != o_masks).any(axis=1).sum())
         sel = np.unpackbits(o_masks.view(np.uint8), axis=1).sum(axis=1)
         assert sel.mean() < 3                                         # the filter discriminates (≈1 bin per read + a few false candidates)
+        oidx = ob.OracleIndex(idx_dir, wl["bins"])
+        o = ob.map_batch(oidx, oibf, c, o_, er, threads=THREADS)
+        _log("config5: oracle (K1 + mapping) on %d reads in %.1f s" % (S, time.time() - t0))
+        oidx.close(); oibf.close()
+        assert_all_fields_equal(dev, o[:3])
+        assert st["items"] == o[3]["items"] and st["raw_matches"] == o[3]["raw_matches"]
+        m = dev[0]["mapped"] == 1
+        assert m.mean() > 0.99 and (dev[0]["primary"]["contig"][m] == truth["bin"][:S][m]).mean() > 0.9999
+        assert (dev[0]["primary"]["errors"][m] > 3).sum() > 100      # wide bands met
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------- the north-star sentence: 64 bins / 16 GiB
+def test_northstar_geometry(dy, ob):
+    """BASELINE.json's target workload on one GPU: 64 bins, a 16 GiB filter, one resident batch of 2 M x 100 bp reads (the 10 M reads are 5
+    such batches; a batch holds at most 2 097 151 reads).  At this fill (0.6 %) k_ibf_query_two takes its first check early (slack 4) and
+    requests no tail k-mers with the first round (the other branch of the kernel from config 2's).  Masks and every field == oracle."""
+    from dream_yara_amd import synth
+    import bench
+    wl = dict(bench.WORKLOADS["northstar"])
+    _, genomes, idx_dir = _inputs("config2")                        # the same 64 genomes and indices as configs[1]
+    ctx = dy.Context(0)
+    try:
+        ibf = _device_filter(dy, ctx, wl, genomes)
+        assert ibf.info()["words_per_pos"] == 1 and ibf.info()["n_bits"] == (16 << 33) + 256
+        index = dy.Index(ctx, idx_dir, wl["bins"])
+        N = wl["batch"]
+        codes, offs, truth = synth.simulate_reads(genomes, N, wl["L"], seed=0x5EED0002 + 7919)
+        er = np.float32(wl["e"] / 100.0)
+        thr = dy.threshold(er, wl["k"], wl["L"])
+        reads = dy.Reads(ctx, codes, offs)
+        d_masks = ibf.query(reads, thr)
+        st = ctx.stats()
+        assert st["ibf_kernel"] == 1 and st["ibf_tail_pre"] == 0 and 1 <= st["ibf_slack"] < 14, st      # config 2 (1 GiB): tail_pre 4, slack >= 14
+        res = dy.map_reads(ctx, index, reads, dy.default_params(error_rate=er))
+        dev = (res.reads(), res.matches(), res.cigars()); st = ctx.stats()
+        res.close(); reads.close(); index.close()
+        oibf = _oracle_filter(ob, ibf)
+        ibf.close()
+        t0 = time.time()
+        o_masks = oibf.query(codes, offs, thr, threads=THREADS)
+        assert np.array_equal(d_masks, o_masks), "K1 masks differ at %d reads" % int((d_masks != o_masks).any(axis=1).sum())
+        oidx = ob.OracleIndex(idx_dir, wl["bins"])
+        o = ob.map_batch(oidx, oibf, codes, offs, er, threads=THREADS)
+        _log("northstar: oracle on %d reads in %.1f s" % (N, time.time() - t0))
+        oidx.close(); oibf.close()
+        assert_all_fields_equal(dev, o[:3])
+        assert st["items"] == o[3]["items"] and st["raw_matches"] == o[3]["raw_matches"]
+        m = dev[0]["mapped"] == 1
+        assert m.mean() > 0.99 and (dev[0]["primary"]["contig"][m] == truth["bin"][m]).mean() > 0.9999
+    finally:
+        ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------- configs[2] / [3] partitioning at their bin count
+@pytest.mark.parametrize("paired", [False, True])
+def test_bins_sharded_two_ranks_at_256_bins(dy, ob, tmp_path, paired):
+    """BASELINE configs[2] / [3] shard 256 bins over the ranks.  Two ranks on this GPU (exchanges over gloo) each hold the FM structures of
+    128 of the 256 x 4 Mbp bins (W = 4 mask words per read); every field of every read equals the single-GPU run on the whole job (which
+    test_config3_geometry_single_end / test_config4_geometry_paired_end tie to the oracle).  The filter is a 1 GiB one here (each worker
+    process loads it from a file); the partitioning does not depend on the filter's size."""
+    from dream_yara_amd import synth
+    from test_gpu_parity import _run_sharded_workers
+    wl, genomes, idx_dir = _inputs("config3")
+    ctx = dy.Context(0)
+    ibf = dy.Ibf.create(ctx, wl["bins"], wl["h"], wl["k"], (1 << 33) + 256)
+    for b, g in enumerate(genomes):
+        ibf.add(g, b)
+    ibf.save(str(tmp_path / "f.filter")); ibf.close(); ctx.close()
+    os.symlink(idx_dir.rstrip("/"), str(tmp_path / "idx"))
+    if paired:
+        codes, offs, _ = synth.simulate_pairs(genomes, 20_000, 100, seed=0x5EED0004 + 1, sub_hi=0.02)
+    else:
+        codes, offs, _ = synth.simulate_reads(genomes, 60_000, 100, seed=0x5EED0003 + 1)
+    del genomes
+    np.savez(str(tmp_path / "reads.npz"), codes=codes, offs=offs)
+    outs = _run_sharded_workers(tmp_path, wl["bins"], wl["k"], 0.0, 29631 + int(paired), ["paired"] if paired else [])
+    n = offs.size - 1
+    assert sum(o["n"] for o in outs) == n and sum(o["mapped"] for o in outs) > 0.95 * n
+    assert all(o["recv_reads"] > 0 and o["raw_in"] > 0 for o in outs)
+    assert sum(o["sent_reads"] for o in outs) == sum(o["recv_reads"] for o in outs) >= 0.99 * n      # a read may select no bin at all
+    if paired:
+        assert all(o["pe_items_in"] > 0 for o in outs) and sum(o["paired_reads"] for o in outs) > 0.9 * n
