@@ -33,6 +33,8 @@ struct CliOptions
     std::vector<int> devices;           // --devices 0,1,...  (default 0..N-1; a device may be listed twice: two contexts on it, used by the tests)
     std::string shard = "reads";        // --shard reads | bins   (multi_gpu.hpp)
     std::string transport = "auto";     // --transport auto | rccl | copy   (bins mode)
+    std::string outputFormat = "sam";   // -f: format of the standard output
+    bool uncompressedBam = false;       // -u
     std::string binAssignment = "lpt";  // --bin-assignment lpt | mod   (bins mode: which device owns which bin)
     int bamLevel = -1;                  // --bam-level 0..9: deflate level of BAM output (default: zlib's, 6)
 };
@@ -71,8 +73,26 @@ CliOptions parse(int argc, char ** argv)
             if (o.filterType != "bloom" && o.filterType != "none" && o.filterType != "kmer_direct") fail("unknown filter type " + o.filterType);
         }
         else if (a == "-o" || a == "--output-file") o.outputFile = value();
+        else if (a == "-f" || a == "--output-format")
+        {   // format of the standard output; with -o the file name's extension decides (reference src/d_mapper.cpp:144-148,306-312, src/d_mapper.h:768-785)
+            o.outputFormat = value();
+            if (o.outputFormat != "sam" && o.outputFormat != "bam") fail("the given value '" + o.outputFormat + "' is not in the list of allowed values for output-format (sam, bam)");
+        }
+        else if (a == "-u" || a == "--uncompressed-bam") o.uncompressedBam = true;                              // :150-153,314-316: BAM on standard output without compression
+        else if (a == "-sa" || a == "--secondary-alignments")
+        {   // kept by the reference only to say so (:165-168,323-327)
+            (void)value();
+            fail("The 'secondary-alignments' option has been renamed to 'secondary-matches'!");
+        }
+        else if (a == "-ra" || a == "--rabema-alignments")
+            // the reference then takes the CIGARs from a unit-cost global alignment (LinearGaps, src/mapper.h:1203, src/mapper_aligner.h:155-160)
+            fail("--rabema-alignments (CIGARs from a unit-cost global alignment instead of the affine one) is not implemented");
         else if (a == "-rg" || a == "--read-group") o.readGroup = value();
-        else if (a == "-sm" || a == "--secondary-matches") value();      // read under a legacy name by the reference: no effect (:320)
+        else if (a == "-sm" || a == "--secondary-matches")
+        {   // validated, then without effect: the reference reads the value under the legacy option's name (:320), so it stays `tag`
+            const std::string v = value();
+            if (v != "tag" && v != "record" && v != "omit") fail("the given value '" + v + "' is not in the list of allowed values for secondary-matches (tag, record, omit)");
+        }
         else if (a == "-t" || a == "--threads") o.hostThreads = uintValue(1, 2048);      // the device replaces the mapping threads; these format the output
         else if (a == "-rb" || a == "--reads-batch") o.readsBatch = uintValue(1000, 5000000);
         else if (a == "-sk" || a == "--skip-sam-headers") o.skipSamHeader = true;
@@ -201,8 +221,10 @@ int main(int argc, char ** argv)
             }
         }
 
-        // output format by extension (reference src/d_mapper.cpp:140-153): .bam -> BGZF-compressed BAM, anything else -> SAM text
-        const bool bam = opt.outputFile.size() >= 4 && opt.outputFile.compare(opt.outputFile.size() - 4, 4, ".bam") == 0;
+        // output format: by extension with -o (reference src/d_mapper.cpp:140-153): .bam -> BGZF-compressed BAM, anything else -> SAM text; -f for the standard output
+        const bool bam = opt.outputFile.empty() ? opt.outputFormat == "bam"
+                                                : (opt.outputFile.size() >= 4 && opt.outputFile.compare(opt.outputFile.size() - 4, 4, ".bam") == 0);
+        if (opt.uncompressedBam && opt.outputFile.empty() && bam) opt.bamLevel = 0;                               // reference src/d_mapper.h:771-776
         std::ofstream ofs;
         if (!opt.outputFile.empty()) { ofs.open(opt.outputFile, bam ? std::ios::binary : std::ios::out); if (!ofs) fail("Error while opening output file."); }
         std::ostream & os = opt.outputFile.empty() ? std::cout : ofs;

@@ -414,7 +414,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
             const u64 nWords = (u64)nReads * W;
             ctx->waveCounts.reserve((size_t)(nReads + 1) * 4); ctx->waveOffsets.reserve((size_t)(nReads + 1) * 4);
             HIP_CHECK(hipMemsetAsync(ctx->waveCounts.p, 0, (size_t)(nReads + 1) * 4, st));
-            if (nWords) hipLaunchKernelGGL(k_items_word_count, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, ctx->waveCounts.as<u32>());
+            if (nWords) hipLaunchKernelGGL(k_items_word_count, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, nBins, ctx->waveCounts.as<u32>());
             size_t tmpBytes = 0;
             HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (int)(nReads + 1), st));
             ctx->scanTmp.reserve(tmpBytes + 64);
@@ -545,7 +545,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
                 // the longest seed a read of the batch can be cut into: a short read with few errors may be ONE seed (ceil((e + 1) / 3) = 1)
                 const u32 maxSeedLen = reads->maxLen;
                 // the kernels for reads of up to 256 bases hold the extension's edit-distance band in one word (myers_device.h): at most 31 errors
-                const bool bandFits = readErrorsOf(reads->maxLen, p->error_rate) <= 31;
+                const bool bandFits = readErrorsOf(reads->maxLen, p->error_rate) <= PREFIX_SEARCH_SMALL_MAX_K;      // the contract of prefixSearch<NW <= 4>
                 if (nw <= 2 && bandFits) launchExtend<2>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 else if (nw <= 4 && bandFits) launchExtend<4>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 else if (nw <= 16) launchExtend<16>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);

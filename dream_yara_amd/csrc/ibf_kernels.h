@@ -4,9 +4,11 @@
 //
 // Mapping: one wavefront per read; lane = k-mer.  A chunk of 64 consecutive k-mers needs 64+k-1 <= 95 bases; the two
 // bit-planes of the 2-bit codes are built with wave ballots (bit t of a plane = base t), so a lane gets its k-mer with
-// two funnel shifts, a bit reversal and a Morton interleave — no LDS, no per-base loop.  Each lane then issues its h*W
-// independent 64-bit gathers (the only HBM traffic that matters: (L-k+1)*h*W*8 B per strand), ANDs them, and the
-// per-bin counts are popcounts of ballots over the bins present in the wave's OR-mask.
+// two funnel shifts, a bit reversal and a Morton interleave — no LDS, no per-base loop.  The look-ups are 64-bit gathers
+// ((L-k+1)*h*W*8 B per strand if none were skipped — the figure the roofline is priced on); every sweep below issues only those
+// that can still change a `count >= threshold` decision.  Per-bin counts: a bit-sliced adder butterfly across the wave for W = 1
+// (waveBitSlicedSum: plane p = bit p of all 64 bin counts, in scalar registers; k_ibf_query_two, k_ibf_query<NP>, k_ibf_query_wide),
+// LDS atomics on one counter per bin with a per-word suspect mask for W > 1 (k_ibf_query_lazy, k_ibf_query_eager2).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dy_types.h"

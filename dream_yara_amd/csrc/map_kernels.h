@@ -248,11 +248,18 @@ __global__ __launch_bounds__(256) void k_items_bin_rank(const u32 * __restrict__
 // matrix of nBins x nReads/64 cells the set bits are emitted as (bin, read) pairs in read order — one thread per mask WORD, coalesced — and
 // a stable radix sort by bin gives the bin-major, read-ascending order; the bin starts are lower bounds in the sorted keys.  Per 1 M reads:
 // 1 024 bins 1.05 -> 0.33 ms, 256 bins 0.245 -> 0.137 ms, 64 bins 0.124 -> 0.114 ms.
-__global__ void k_items_word_count(const u64 * __restrict__ masks, u64 nWords, u32 W, u32 * __restrict__ readCount)
+// bits at or above nBins in a read's last word are not bins: both passes ignore them (every producer of masks clears them, but a count that
+// disagreed with the emit would feed uninitialised pairs to the sort)
+__device__ __forceinline__ u64 binBitsOfWord(u64 m, u32 w, u32 nBins)
+{
+    const u32 left = nBins - w * 64;                   // w < W = ceil(nBins / 64), so left >= 1
+    return left >= 64 ? m : m & ((1ull << left) - 1);
+}
+__global__ void k_items_word_count(const u64 * __restrict__ masks, u64 nWords, u32 W, u32 nBins, u32 * __restrict__ readCount)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nWords) return;
-    const u64 m = masks[t];
+    const u64 m = binBitsOfWord(masks[t], (u32)(t % W), nBins);
     if (m) atomicAdd(&readCount[t / W], (u32)__popcll(m));
 }
 
@@ -597,6 +604,7 @@ static_assert(sizeof(EditFrame) == 16, "frame slab stride");
 template <typename TLeaf>
 __device__ void fmBacktrackEdit(const BinView & b, const u8 * __restrict__ seq, u32 len, u32 strand, u32 off, u32 seedLen, u32 maxErr, EditFrame * __restrict__ st, TLeaf leaf)
 {
+    if (maxErr > 2) return;          // a frame's band holds 2 * 2 + 1 cells: seed errors are 1 or 2 (reference src/mapper_classifier.h:141-149); the host refuses larger budgets
     const u32 E = maxErr, BW = 2 * E + 1, INF = E + 1;
     int level = 0;
     st[0].lo = 0; st[0].hi = b.n; st[0].alt = 0;

@@ -143,11 +143,16 @@ __device__ __forceinline__ void myersPrefixSearchBanded(TNeedle needle, int m, T
 
 // What K3 calls: the banded form wherever one word holds the band.  NW = 64-bit words that cover the longest needle of the batch: reads of
 // up to 256 bases (NW <= 4) carry at most 25 errors (the error rate is capped at 10 %), so their kernels never need the block form.
+// CONTRACT of the small instantiations (NW <= 4): k <= PREFIX_SEARCH_SMALL_MAX_K.  They leave the block form out (its registers would cost
+// K3 a wave per SIMD), so the host must not launch them with a larger error budget: runSearchExtend (dyhip.hip) dispatches on this very
+// constant (`bandFits`), and tests/native/myers_fuzz.cpp checks the dispatcher against a plain DP up to k = 40 for NW = 16 and up to the
+// bound for NW = 2 / 4.  The clamp below only keeps a violated contract from shifting by more than the word: it would lose matches.
+enum { PREFIX_SEARCH_SMALL_MAX_K = 31 };
 template <int NW, typename TNeedle, typename TText, typename TReport>
 __device__ __forceinline__ void prefixSearch(TNeedle needle, int m, TText text, int t, int k, TReport report)
 {
     if (k <= 15) myersPrefixSearchBanded<u32>(needle, m, text, t, k, report);
-    else if (NW <= 4 || k <= 31) myersPrefixSearchBanded<u64>(needle, m, text, t, k < 31 ? k : 31, report);
+    else if (NW <= 4 || k <= 31) myersPrefixSearchBanded<u64>(needle, m, text, t, k < PREFIX_SEARCH_SMALL_MAX_K ? k : (int)PREFIX_SEARCH_SMALL_MAX_K, report);
     else myersPrefixSearch<NW>(needle, m, text, t, k, report);
 }
 

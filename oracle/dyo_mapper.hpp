@@ -11,6 +11,7 @@
 // PINNED by: tests/golden/gold/64-viral-reads.{t1,rec.t1,tag.t1}.sam (SE, -e 3, strata 0 and 10).
 // UNPINNED: paired-end, -y full, L=150/e=7 tail behaviour (no reference gold exists).
 #pragma once
+#include <stdexcept>
 #include "dyo_formats.hpp"
 #include "dyo_indexer.hpp"
 #include <cmath>
@@ -216,6 +217,7 @@ inline void fmSearch(const FMIndex & fm, const u8 * seed, unsigned len, unsigned
 inline void fmSearchEdit(const FMIndex & fm, const u8 * seed, unsigned len, unsigned maxErr, u32 seedId, std::vector<Hit> & hits)
 {
     const unsigned E = maxErr, BW = 2 * E + 1, INF = E + 1;
+    if (maxErr > 2) throw std::logic_error("fmSearchEdit: the band of a frame holds 2 * 2 + 1 cells (seed errors are 1 or 2, reference src/mapper_classifier.h:141-149)");
     struct Frame { u32 lo, hi; u8 alt; u8 band[5]; };
     std::vector<Frame> st(len + E + 2);
     int level = 0;

@@ -94,6 +94,42 @@ int main(int argc, char ** argv)
             if (gotBlock != want) { printf("BLOCK MISMATCH it=%d k=%d m=%d\n", it, k, m); return 1; }
         }
     }
-    printf("ok banded=%ld block=%ld with_reports=%ld\n", checkedBanded, checkedBlock, withReports);
+    // the dispatcher K3 calls: every branch of prefixSearch<16> (one-word band up to 15 / 31 errors, block form beyond: budgets up to 40), and the
+    // small instantiations up to their contract bound
+    long checkedDispatch = 0;
+    for (int it = 0; it < rounds / 4; ++it)
+    {
+        const int k = (int)(rng() % 41);
+        const int m = (int)(rng() % (it % 3 == 0 ? 900 : 120));
+        const int alpha = it % 5 == 0 ? 2 : 4;
+        std::vector<u8> needle(m);
+        for (auto & c : needle) c = (u8)(rng() % alpha);
+        std::vector<u8> text(needle);
+        const int edits = (int)(rng() % (k + 3));
+        for (int e = 0; e < edits && !text.empty(); ++e)
+        {
+            const size_t p = rng() % text.size();
+            switch (rng() % 3)
+            {
+                case 0: text[p] = (u8)(rng() % alpha); break;
+                case 1: text.insert(text.begin() + p, (u8)(rng() % alpha)); break;
+                default: text.erase(text.begin() + p); break;
+            }
+        }
+        for (int e = (int)(rng() % 50); e > 0; --e) text.push_back((u8)(rng() % alpha));
+        const Reports want = plainDp(needle, text, k);
+        auto nd = [&](int i) -> u32 { return needle[(size_t)i]; };
+        auto tx = [&](int j) -> u32 { return text[(size_t)j]; };
+        Reports got;
+        auto rep = [&](int pos, int dist) { got.push_back({pos, dist}); };
+        if (m <= 1024) { prefixSearch<16>(nd, m, tx, (int)text.size(), k, rep); ++checkedDispatch; if (got != want) { printf("DISPATCH<16> MISMATCH it=%d k=%d m=%d\n", it, k, m); return 1; } }
+        if (k <= PREFIX_SEARCH_SMALL_MAX_K && m <= 256)
+        {
+            got.clear(); prefixSearch<4>(nd, m, tx, (int)text.size(), k, rep); ++checkedDispatch;
+            if (got != want) { printf("DISPATCH<4> MISMATCH it=%d k=%d m=%d\n", it, k, m); return 1; }
+            if (m <= 128) { got.clear(); prefixSearch<2>(nd, m, tx, (int)text.size(), k, rep); ++checkedDispatch; if (got != want) { printf("DISPATCH<2> MISMATCH it=%d k=%d m=%d\n", it, k, m); return 1; } }
+        }
+    }
+    printf("ok banded=%ld block=%ld dispatch=%ld with_reports=%ld\n", checkedBanded, checkedBlock, checkedDispatch, withReports);
     return 0;
 }

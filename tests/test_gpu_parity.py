@@ -830,6 +830,14 @@ def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
     assert bam_to_sam_lines(bam1)[2] == recs and os.path.getsize(bam1) > os.path.getsize(bam)
     assert sam_records(sam_gz) == sam_records(sam)
     assert sam_records(sam) == sam_records(os.path.join(GOLDEN, "gold", "64-viral-reads.tag.t1.sam"))
+    # -f: the format of the standard output (reference src/d_mapper.cpp:144-148,306-312); -u: that BAM uncompressed (:150-153, src/d_mapper.h:771-776)
+    out_bam, out_ubam, out_sam = str(tmp_path / "stdout.bam"), str(tmp_path / "stdout_u.bam"), str(tmp_path / "stdout.sam")
+    for path, extra in ((out_bam, ["-f", "bam"]), (out_ubam, ["-f", "bam", "-u"]), (out_sam, ["--output-format", "sam", "-sm", "record"])):
+        with open(path, "wb") as fo:
+            subprocess.check_call(base + [READS_FA] + extra, stdout=fo)
+    assert bam_to_sam_lines(out_bam)[2] == recs and bam_to_sam_lines(out_ubam)[2] == recs
+    assert os.path.getsize(out_ubam) > 2 * os.path.getsize(out_bam)                      # stored, not deflated
+    assert sam_records(out_sam) == sam_records(sam)
 
 
 @pytest.mark.gpu
@@ -1240,6 +1248,17 @@ def test_cli_errors_exit_1_with_the_tool_name(product_build, small_filter, tmp_p
     assert rc == 1 and err.startswith("dream_yara_mapper: ")
     rc, err = run([GOLD_INDEX + "/"])
     assert rc == 1
+    # the legacy option the reference keeps only to say so (src/d_mapper.cpp:165-168,323-327)
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-sa", "tag"])
+    assert rc == 1 and err.strip() == "dream_yara_mapper: The 'secondary-alignments' option has been renamed to 'secondary-matches'!"
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-f", "cram"])
+    assert rc == 1 and "output-format" in err
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-sm", "all"])
+    assert rc == 1 and "secondary-matches" in err
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-ra"])
+    assert rc == 1 and "not implemented" in err                                       # parsed, and refused in so many words
+    rc, err = run(["-fi", small_filter, GOLD_INDEX + "/", READS_FA, "-b", "64"])
+    assert rc == 1 and "unknown option" in err                                        # commented out in the reference's parser too (src/d_mapper.cpp:247-251)
 
 
 # ---------------------------------------------------------------------------------------------- bins sharded over ranks
