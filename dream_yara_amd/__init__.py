@@ -89,6 +89,10 @@ SYMBOLS = [
     ("dy_ibf_query", C.c_int, [_P, _P, C.c_uint16, _P]),
     ("dy_ibf_query_deferred", C.c_int, [_P, _P, C.c_uint16]),
     ("dy_ctx_background_chunk", C.c_int, [_P, C.c_uint32]),
+    ("dy_host_buffer", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
+    ("dy_reads_from_fastq", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("dy_reads_total_bases", C.c_uint64, [_P]),
+    ("dy_result_sam", C.c_int, [_P, _P, _P, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("dy_reads_select_all_bins", C.c_int, [_P, _P, C.c_uint32]),
     ("dy_suffix_array", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P]),
     ("dy_index_load", C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(_P)]),
@@ -261,6 +265,17 @@ def threshold(error_rate, kmer_size, read_len):
 
 class Reads:
     @classmethod
+    def from_fastq(cls, ctx, text, max_reads, at_eof=True):
+        """The first max_reads four-line FASTQ records of `text` (bytes), parsed on the device.  Returns (Reads, bytes consumed)."""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        h, used = _P(), C.c_uint64(0)
+        _check(ctx.lib.dy_reads_from_fastq(ctx.h, buf.ctypes.data if buf.size else None, buf.size, max_reads, 1 if at_eof else 0, C.byref(h), C.byref(used)))
+        return cls._from_handle(ctx, h), int(used.value)
+
+    def total_bases(self):
+        return int(self.lib.dy_reads_total_bases(self.h))
+
+    @classmethod
     def _from_handle(cls, ctx, handle):
         self = cls.__new__(cls)
         self.ctx, self.lib, self.h = ctx, ctx.lib, handle
@@ -360,6 +375,14 @@ class Result:
             return np.zeros(0, dtype=np.uint32)
         buf = (C.c_char * (n * 4)).from_address(ptr)
         return np.frombuffer(buf, dtype=np.uint32).copy()
+
+    def sam(self, reads, index, read_group="none", slot=0):
+        """The batch's SAM records (single-end, reads from Reads.from_fastq), formatted on the device.  Returns (bytes, mapped reads)."""
+        text, n, m = C.c_char_p(), C.c_uint64(0), C.c_uint64(0)
+        ptr = C.cast(C.pointer(text), C.POINTER(C.c_char_p))
+        _check(self.lib.dy_result_sam(self.h, reads.h, index.h, read_group.encode(), slot, ptr, C.byref(n), C.byref(m)))
+        addr = C.cast(text, C.c_void_p).value
+        return (C.string_at(addr, n.value) if n.value else b""), int(m.value)
 
     def close(self):
         if self.h:

@@ -6,6 +6,12 @@
 #include "bam_writer.hpp"
 #include "multi_gpu.hpp"
 #include <charconv>
+#include <condition_variable>
+#include <mutex>
+#include <cerrno>
+#include <cstdlib>
+#include <fcntl.h>
+#include <unistd.h>
 #include <iostream>
 #include <fstream>
 #include <sstream>
@@ -25,7 +31,7 @@ struct CliOptions
     std::string indicesDir, readsFile, readsFile2, outputFile, filterFile, filterType = "bloom", readGroup = "none";
     dy_params params;
     unsigned readsBatch = 100000;
-    unsigned hostThreads = 0;          // 0 = min(16, hardware threads)
+    unsigned hostThreads = 0;          // 0 = min(32, hardware threads)
     bool verbose = false, skipSamHeader = false;
     std::string commandLine;
     // ---- not in the reference (its -t threads share one address space): devices of this node
@@ -36,6 +42,9 @@ struct CliOptions
     std::string outputFormat = "sam";   // -f: format of the standard output
     bool uncompressedBam = false;       // -u
     std::string binAssignment = "lpt";  // --bin-assignment lpt | mod   (bins mode: which device owns which bin)
+    bool inputInPlace = false;          // --input-in-place: parse the memory-mapped reads file where it lies instead of a private copy of each window
+    bool hostIo = false;                // --host-io: parse FASTQ and format SAM on the host threads even where the device could (single-end, four-line FASTQ in, SAM out)
+    bool teardown = false;              // --teardown: release every device / host object and shut the runtime down in order before exiting
     int bamLevel = -1;                  // --bam-level 0..9: deflate level of BAM output (default: zlib's, 6)
 };
 
@@ -107,6 +116,9 @@ CliOptions parse(int argc, char ** argv)
             std::stringstream ss(value()); std::string tok;
             while (std::getline(ss, tok, ',')) { try { o.devices.push_back(std::stoi(tok)); } catch (...) { fail("--devices takes a comma-separated list of device ordinals"); } }
         }
+        else if (a == "--teardown") o.teardown = true;
+        else if (a == "--host-io") o.hostIo = true;
+        else if (a == "--input-in-place") o.inputInPlace = true;
         else if (a == "--bam-level") o.bamLevel = (int)uintValue(0, 9);
         else if (a == "--shard") { o.shard = value(); if (o.shard != "reads" && o.shard != "bins") fail("--shard takes reads or bins"); }
         else if (a == "--bin-assignment") { o.binAssignment = value(); if (o.binAssignment != "lpt" && o.binAssignment != "mod") fail("--bin-assignment takes lpt or mod"); }
@@ -141,6 +153,54 @@ int main(int argc, char ** argv)
         // bins are sharded when there is something to shard over — or when a transport is named, which runs the whole exchange sequence
         // on one device too (a self send/receive through RCCL: the only RCCL rehearsal a one-GPU box allows)
         const bool shardBins = opt.shard == "bins" && (opt.gpus > 1 || opt.transport != "auto");
+        const unsigned hostThreads = opt.hostThreads ? opt.hostThreads : std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        // ---- input side first: the first round of batches is parsed while the devices load the filter and the index
+        ReadsFile in(opt.readsFile);
+        std::unique_ptr<ReadsFile> in2;
+        if (opt.params.paired) in2.reset(new ReadsFile(opt.readsFile2));
+        in.copyWindow = !opt.inputInPlace; if (in2) in2->copyWindow = !opt.inputInPlace;
+        if (opt.params.paired && opt.readsBatch > 1048575) opt.readsBatch = 1048575;      // both mates share the 21-bit read id space
+        // A batch is mapped in PARTS: one part = the whole batch on one device (--shard reads: consecutive batches go to consecutive
+        // devices) or, with --shard bins, the slice of the batch that is at home on a device.  A part covers reads [lo, hi) (single-end)
+        // or pairs [lo, hi) = reads [lo, hi) + [P + lo, P + hi) (paired).  Three ROUNDS of up to N batches are in flight: one being
+        // parsed, one on the devices, one being formatted and written (in input order).
+        struct Part { size_t lo = 0, hi = 0; unsigned dev = 0; dy_reads * reads = nullptr; dy_result * res = nullptr; std::vector<u8> codes; std::vector<u64> offs; };
+        struct Slot { ReadsBatch batch; size_t nPairs = 0; std::vector<Part> parts; };
+        struct Round { std::vector<Slot> slots; size_t used = 0; };
+        const unsigned perRound = shardBins ? 1u : N;
+        Round rounds[3];
+        for (auto & r : rounds) r.slots.resize(perRound);
+        unsigned long long total = 0, mapped = 0;
+        double mapSeconds = 0, parseSeconds = 0, formatSeconds = 0, writeSeconds = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
+        auto readInto = [&](Slot & sl) -> bool {
+            ReadsBatch & batch = sl.batch;
+            if (!in.next(batch, opt.readsBatch, hostThreads)) return false;
+            if (in2)
+            {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
+                ReadsBatch second;
+                if (in2->next(second, batch.size(), hostThreads) != batch.size()) fail("the two reads files hold different numbers of records");
+                batch.append(second);
+            }
+            sl.nPairs = batch.size() / 2;
+            return true;
+        };
+        auto readRound = [&](Round & rd) -> bool {
+            const auto p0 = now();
+            rd.used = 0;
+            while (rd.used < rd.slots.size() && readInto(rd.slots[rd.used])) ++rd.used;
+            parseSeconds += since(p0);
+            return rd.used > 0;
+        };
+        // Device I/O (single-end, uncompressed four-line FASTQ in, SAM out, one device): the reads file goes to the device as bytes and the SAM
+        // records come back as bytes (dy_reads_from_fastq / dy_result_sam) — the host threads only move them.  Anything else, and any batch the
+        // device parser refuses, takes the host path below.
+        const bool bam = opt.outputFile.empty() ? opt.outputFormat == "bam"
+                                                : (opt.outputFile.size() >= 4 && opt.outputFile.compare(opt.outputFile.size() - 4, 4, ".bam") == 0);
+        const bool deviceIo = !opt.hostIo && !opt.params.paired && !bam && N == 1 && opt.shard != "bins" && in.plainFastq();
+        std::future<bool> firstRead;
+        if (!deviceIo) firstRead = std::async(std::launch::async, [&] { return readRound(rounds[0]); });
         // one context (+ filter + index) per listed device
         struct Device { int ordinal = 0; dy_ctx * ctx = nullptr; dy_ibf * ibf = nullptr; dy_index * idx = nullptr; };
         std::vector<Device> devs(N);
@@ -222,12 +282,24 @@ int main(int argc, char ** argv)
         }
 
         // output format: by extension with -o (reference src/d_mapper.cpp:140-153): .bam -> BGZF-compressed BAM, anything else -> SAM text; -f for the standard output
-        const bool bam = opt.outputFile.empty() ? opt.outputFormat == "bam"
-                                                : (opt.outputFile.size() >= 4 && opt.outputFile.compare(opt.outputFile.size() - 4, 4, ".bam") == 0);
         if (opt.uncompressedBam && opt.outputFile.empty() && bam) opt.bamLevel = 0;                               // reference src/d_mapper.h:771-776
+        // SAM into a file goes through a plain descriptor (no stream buffer in between: the chunks are hundreds of MB)
         std::ofstream ofs;
-        if (!opt.outputFile.empty()) { ofs.open(opt.outputFile, bam ? std::ios::binary : std::ios::out); if (!ofs) fail("Error while opening output file."); }
+        int samFd = -1; uint64_t samOffset = 0;
+        if (!opt.outputFile.empty())
+        {
+            if (bam) { ofs.open(opt.outputFile, std::ios::binary); if (!ofs) fail("Error while opening output file."); }
+            else { samFd = ::open(opt.outputFile.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666); if (samFd < 0) fail("Error while opening output file."); }
+        }
         std::ostream & os = opt.outputFile.empty() ? std::cout : ofs;
+        auto writeAll = [&](int fd, const char * p, size_t n, uint64_t at) {
+            while (n)
+            {
+                const ssize_t w = ::pwrite(fd, p, n, (off_t)at);
+                if (w < 0) { if (errno == EINTR) continue; fail("Error while writing the output file."); }
+                p += w; n -= (size_t)w; at += (uint64_t)w;
+            }
+        };
         std::vector<std::string> contigNames; std::vector<uint64_t> contigLengths;
         for (uint32_t c = 0; c < dy_index_contigs(idx); ++c) { contigNames.push_back(dy_index_contig_name(idx, c)); contigLengths.push_back(dy_index_contig_length(idx, c)); }
         std::string headerText;
@@ -239,47 +311,10 @@ int main(int argc, char ** argv)
             for (size_t c = 0; c < contigNames.size(); ++c) headerText += "@SQ\tSN:" + contigNames[c] + "\tLN:" + std::to_string(contigLengths[c]) + "\n";
         }
         BgzfWriter bgzf(os, opt.bamLevel);
-        const unsigned hostThreads = opt.hostThreads ? opt.hostThreads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
         if (bam) bamWriteHeader(bgzf, headerText, contigNames, contigLengths);
+        else if (samFd >= 0) { writeAll(samFd, headerText.data(), headerText.size(), 0); samOffset = headerText.size(); }
         else os << headerText;
 
-        ReadsFile in(opt.readsFile);
-        std::unique_ptr<ReadsFile> in2;
-        if (opt.params.paired) in2.reset(new ReadsFile(opt.readsFile2));
-        if (opt.params.paired && opt.readsBatch > 1048575) opt.readsBatch = 1048575;      // both mates share the 21-bit read id space
-        // A batch is mapped in PARTS: one part = the whole batch on one device (--shard reads: consecutive batches go to consecutive
-        // devices) or, with --shard bins, the slice of the batch that is at home on a device.  A part covers reads [lo, hi) (single-end)
-        // or pairs [lo, hi) = reads [lo, hi) + [P + lo, P + hi) (paired).  Three ROUNDS of up to N batches are in flight: one being
-        // parsed, one on the devices, one being formatted and written (in input order).
-        struct Part { size_t lo = 0, hi = 0; unsigned dev = 0; dy_reads * reads = nullptr; dy_result * res = nullptr; std::vector<u8> codes; std::vector<u64> offs; };
-        struct Slot { ReadsBatch batch; size_t nPairs = 0; std::vector<Part> parts; };
-        struct Round { std::vector<Slot> slots; size_t used = 0; };
-        const unsigned perRound = shardBins ? 1u : N;
-        Round rounds[3];
-        for (auto & r : rounds) r.slots.resize(perRound);
-        unsigned long long total = 0, mapped = 0;
-        double mapSeconds = 0, parseSeconds = 0, formatSeconds = 0, writeSeconds = 0;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); };
-        auto readInto = [&](Slot & sl) -> bool {
-            ReadsBatch & batch = sl.batch;
-            if (!in.next(batch, opt.readsBatch, hostThreads)) return false;
-            if (in2)
-            {   // readRecords of a file pair: first mates, then second mates (reference src/file_pair.h:81-88)
-                ReadsBatch second;
-                if (in2->next(second, batch.size(), hostThreads) != batch.size()) fail("the two reads files hold different numbers of records");
-                batch.append(second);
-            }
-            sl.nPairs = batch.size() / 2;
-            return true;
-        };
-        auto readRound = [&](Round & rd) -> bool {
-            const auto p0 = now();
-            rd.used = 0;
-            while (rd.used < rd.slots.size() && readInto(rd.slots[rd.used])) ++rd.used;
-            parseSeconds += since(p0);
-            return rd.used > 0;
-        };
         // batch index of part-local read j
         auto batchIndex = [&](const Slot & sl, const Part & pt, size_t j) -> size_t {
             if (!opt.params.paired) return pt.lo + j;
@@ -395,6 +430,11 @@ int main(int argc, char ** argv)
         auto formatRound = [&](Round & rd) { Formatted f; for (size_t i = 0; i < rd.used; ++i) formatSlot(rd.slots[i], f); return f; };
         auto writeFormatted = [&](Formatted f) {
             const auto w0 = now();
+            if (!bam && samFd >= 0)
+            {   // one writer: buffered writes to one file serialise on the inode lock (scripts/ubench/write_paths.cpp: 11 GB/s from one thread, 9 from eight)
+                for (Chunk & ch : f.chunks) { writeAll(samFd, ch.sam.data(), ch.sam.size(), samOffset); samOffset += ch.sam.size(); mapped += ch.nMapped; }
+            }
+            else
             for (Chunk & ch : f.chunks)
             {
                 if (bam) bgzf.writeParallel(ch.bam.data(), ch.bam.size(), hostThreads);
@@ -488,14 +528,133 @@ int main(int argc, char ** argv)
         std::future<Formatted> formatter;
         std::future<void> writer;
         int formatting = -1;
+        double waitFormat = 0, waitWrite = 0, waitRead = 0, releaseSeconds = 0;
         auto retireFormatter = [&] {
+            auto w0 = now();
             Formatted f = formatter.get();
+            waitFormat += since(w0); w0 = now();
             releaseRound(rounds[formatting]); formatting = -1;
+            releaseSeconds += since(w0); w0 = now();
             if (writer.valid()) writer.get();
+            waitWrite += since(w0);
             writer = std::async(std::launch::async, [&writeFormatted, f = std::move(f)]() mutable { writeFormatted(std::move(f)); });
         };
+        double ioRead = 0, ioWrite = 0, ioParse = 0, ioMap = 0, ioFormat = 0, ioWaitRead = 0, ioWaitWrite = 0;
+        if (deviceIo)
+        {   // ---- three threads, two pinned slots each way: read window j+1 | parse, map, format batch k on the device | write batch k-1
+            Device & D = devs[0];
+            const size_t fileSize = in.fileSize();
+            std::mutex m; std::condition_variable cv;
+            // reader: request j = (start, bytes) -> pinned slot j & 1 filled.  Request j + 1 is issued once window j has been parsed (its bytes are on
+            // the device and the batch's end in the file is known), so the read of the next window runs beside the mapping of this batch.
+            size_t reqStart[2] = {0, 0}, reqBytes[2] = {0, 0}; int issued = 0, filled = 0; bool stop = false;
+            void * inSlot[2] = {nullptr, nullptr};
+            std::string readerError, writerError;
+            std::thread reader([&] {
+                try
+                {
+                    for (int j = 0;; ++j)
+                    {
+                        size_t start, bytes;
+                        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return issued > j || stop; }); if (issued <= j) return; start = reqStart[j & 1]; bytes = reqBytes[j & 1]; }
+                        const auto r0 = now();
+                        void * buf = nullptr;
+                        check(dy_host_buffer(D.ctx, (uint32_t)(j & 1), bytes, &buf));
+                        if (bytes && !in.readRaw((u8 *)buf, start, bytes, 2)) fail("Error while reading the reads file.");
+                        { std::lock_guard<std::mutex> lk(m); ioRead += since(r0); inSlot[j & 1] = buf; filled = j + 1; }
+                        cv.notify_all();
+                    }
+                }
+                catch (std::exception const & e) { std::lock_guard<std::mutex> lk(m); readerError = e.what(); cv.notify_all(); }
+            });
+            // writer: the SAM text of batch k lies in pinned slot 2 + (k & 1)
+            const char * outText[2] = {nullptr, nullptr}; uint64_t outBytes[2] = {0, 0}; int produced = 0, written = 0;
+            std::thread writerThread([&] {
+                try
+                {
+                    for (int k = 0;; ++k)
+                    {
+                        const char * t; uint64_t n;
+                        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return produced > k || stop; }); if (produced <= k) return; t = outText[k & 1]; n = outBytes[k & 1]; }
+                        const auto w0 = now();
+                        if (samFd >= 0) { writeAll(samFd, t, (size_t)n, samOffset); samOffset += n; }
+                        else os.write(t, (std::streamsize)n);
+                        { std::lock_guard<std::mutex> lk(m); ioWrite += since(w0); written = k + 1; }
+                        cv.notify_all();
+                    }
+                }
+                catch (std::exception const & e) { std::lock_guard<std::mutex> lk(m); writerError = e.what(); cv.notify_all(); }
+            });
+            auto request = [&](size_t start, size_t bytes) { { std::lock_guard<std::mutex> lk(m); reqStart[issued & 1] = start; reqBytes[issued & 1] = bytes; ++issued; } cv.notify_all(); };
+            size_t pos = 0; bool fellBack = false; std::string failure;
+            try
+            {
+                size_t window = std::min<size_t>(fileSize, (size_t)opt.readsBatch * 512 + 65536);
+                request(0, window);
+                int k = 0;
+                for (int j = 0; pos < fileSize; ++j)
+                {
+                    const auto dw = now();
+                    { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return filled > j || !readerError.empty(); }); if (!readerError.empty()) fail(readerError); }
+                    auto d0 = now();
+                    ioWaitRead += since(dw); 
+                    const size_t bytes = reqBytes[j & 1];
+                    const bool atEof = pos + bytes >= fileSize;
+                    dy_reads * reads = nullptr; uint64_t consumed = 0;
+                    const int rc = dy_reads_from_fastq(D.ctx, inSlot[j & 1], bytes, opt.readsBatch, atEof ? 1u : 0u, &reads, &consumed);
+                    if (rc == DY_EUNSUPPORTED) { fellBack = true; break; }                            // the rest of the file goes through the host parser
+                    check(rc);
+                    const uint32_t n = dy_reads_count(reads);
+                    if (n == 0 && atEof) { dy_reads_free(reads); break; }                             // nothing but an incomplete record is left: the host parser reports it
+                    if (n < opt.readsBatch && !atEof)
+                    {   // the window held fewer complete records than a batch: once more, larger
+                        dy_reads_free(reads);
+                        window = std::min(fileSize - pos, bytes + bytes / 2 + 65536);
+                        request(pos, window);
+                        continue;
+                    }
+                    ioParse += since(d0); d0 = now();
+                    pos += consumed;
+                    window = std::min(fileSize - pos, (size_t)((double)consumed / (double)n * opt.readsBatch * 1.03) + 65536);
+                    if (pos < fileSize) request(pos, window);                                         // read while this batch is mapped
+                    if (D.ibf)
+                    {
+                        const uint16_t avg = (uint16_t)(dy_reads_total_bases(reads) * 2 / ((uint64_t)n * 2));          // reference src/d_mapper.h:313-315
+                        dy_ibf_info info; check(dy_ibf_get_info(D.ibf, &info));
+                        const uint16_t thr = dy_ibf_threshold(opt.params.error_rate, info.kmer_size, avg);
+                        if (thr == 0) std::cerr << "[WARNING!] 0 k-mer is required to filter a read!\nAll reads will pass filteration and be mapped everywhere.\n";
+                        check(dy_ibf_query(D.ibf, reads, thr, nullptr));
+                    }
+                    dy_result * res = nullptr;
+                    int rm = dy_map_reads_async(D.ctx, D.idx, reads, &opt.params, &res);
+                    if (rm != DY_OK) { dy_reads_free(reads); check(rm); }
+                    ioMap += since(d0); d0 = now();
+                    { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return written >= k - 1 || !writerError.empty(); }); if (!writerError.empty()) fail(writerError); }   // slot of batch k - 2 is free
+                    ioWaitWrite += since(d0); d0 = now();
+                    const char * text = nullptr; uint64_t nBytes = 0, nMapped = 0;
+                    const int rs = dy_result_sam(res, reads, D.idx, opt.readGroup.c_str(), (uint32_t)(2 + (k & 1)), &text, &nBytes, &nMapped);
+                    dy_result_free(res); dy_reads_free(reads);
+                    if (rs == DY_EUNSUPPORTED) { pos -= consumed; fellBack = true; break; }           // (a mapping quality on a rounding boundary: the host formats from here on)
+                    check(rs);
+                    total += n; mapped += nMapped;
+                    ioFormat += since(d0);
+                    { std::lock_guard<std::mutex> lk(m); outText[k & 1] = text; outBytes[k & 1] = nBytes; produced = k + 1; }
+                    cv.notify_all();
+                    ++k;
+                }
+                { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return written >= k || !writerError.empty(); }); }
+            }
+            catch (std::exception const & e) { failure = e.what(); }
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            cv.notify_all();
+            reader.join(); writerThread.join();
+            if (!failure.empty()) fail(failure);
+            if (!writerError.empty()) fail(writerError);
+            mapSeconds += ioParse + ioMap + ioFormat; parseSeconds += ioRead; writeSeconds += ioWrite;
+            if (fellBack || pos < fileSize) { in.seek(pos); firstRead = std::async(std::launch::async, [&] { return readRound(rounds[0]); }); }
+        }
         int cur = 0;
-        bool have = readRound(rounds[cur]);
+        bool have = firstRead.valid() ? firstRead.get() : false;
         while (have)
         {
             const int nxt = (cur + 1) % 3;
@@ -505,13 +664,14 @@ int main(int argc, char ** argv)
             if (formatting >= 0) retireFormatter();
             formatter = std::async(std::launch::async, [&, cur] { return formatRound(rounds[cur]); });
             formatting = cur;
-            have = reader.get();
+            { const auto w0 = now(); have = reader.get(); waitRead += since(w0); }
             cur = nxt;
         }
         if (formatting >= 0) retireFormatter();
         if (writer.valid()) writer.get();
         if (bam) bgzf.finish();
         os.flush();
+        if (samFd >= 0 && ::close(samFd) != 0) fail("Error while writing the output file.");
         if (opt.verbose)
         {
             dy_map_stats s; dy_map_get_stats(devs[0].ctx, &s);
@@ -519,9 +679,18 @@ int main(int argc, char ** argv)
                       << "Loading time:\t\t\t" << std::chrono::duration<double>(t1 - t0).count() << " sec\n"
                       << "Mapping time:\t\t\t" << mapSeconds << " sec\n"
                       << "Parse / format / write time (overlapped with mapping):\t" << parseSeconds << " / " << formatSeconds << " / " << writeSeconds << " sec\n"
+                      << "Device I/O path: upload + parse / sweep + map / format + download " << ioParse << " / " << ioMap << " / " << ioFormat << " sec, waited for the reader / writer " << ioWaitRead << " / " << ioWaitWrite << " sec\n"
+                      << "Main loop waited for parse / format / write / release:\t" << waitRead << " / " << waitFormat << " / " << waitWrite << " / " << releaseSeconds << " sec\n"
+                      << "Since start:\t\t\t" << std::chrono::duration<double>(now() - t0).count() << " sec\n"
                       << "Total reads:\t\t\t" << total << "\nMapped reads:\t\t\t" << mapped << "\n"
                       << "Last batch (device 0): items " << s.items << ", raw matches " << s.raw_matches << ", hard items " << s.hard_items
                       << ", ms ibf/items/search/extend/finalize " << s.ms_ibf << "/" << s.ms_items << "/" << s.ms_search << "/" << s.ms_extend << "/" << s.ms_finalize << "\n";
+        }
+        if (!opt.teardown)
+        {   // every byte is out: the tens of GB on the devices and in host vectors go back with the process (releasing them one by one and
+            // shutting the HIP runtime down in order costs 0.4 s, a quarter of a 16 M-read run); --teardown keeps the orderly exit
+            std::cout.flush(); std::cerr.flush();
+            std::_Exit(0);
         }
         ranks.clear(); exchange.reset();
         for (auto & D : devs)

@@ -21,6 +21,7 @@
 #include "pe_kernels.h"
 #include "shard_kernels.h"
 #include "sa_kernels.h"
+#include "sam_kernels.h"
 
 using namespace dy;
 
@@ -160,6 +161,8 @@ struct dy_ctx
     size_t poolCap = 0;
     PinnedBuf hostUp;                   // staging of dy_reads_upload
     PinnedBuf hostCounters, hostItems;
+    PinnedBuf hostSlots[8];             // dy_host_buffer: pinned host memory the caller reads files into / writes files from (FASTQ in, SAM out)
+    DevBuf fqBlockCount, fqBlockOff, fqLineEnds, fqLensWide, fqLens16, fqStatus, samSizes, samOff, samMapq, samText, samFlags, samGroup;
     PinnedBuf hostStatus;               // small device -> host fetches (counters, flags): pinned, so that a fetch is one copy + one synchronisation
     PinnedBuf sparePinned[9];           // host arrays of fetched results, handed back by dy_result_free (hipHostMalloc costs milliseconds)
     DevBuf sortKeys;                    // k_finalize_t<BlockGroup>: 128-bit sort keys of reads with more than SORT_CAP matches
@@ -277,8 +280,9 @@ struct dy_reads
     u32 maskBins = 0;
     hipEvent_t evK1[2] = {nullptr, nullptr};   // begin / end of the last dy_ibf_query on these reads (on the context's sweep stream)
     bool k1Pending = false;                    // the masks are being written by a sweep that nobody has waited for yet
-    DevBuf orig;          // dy_reads_from_device_paired: arrival index of every read (the batch is re-ordered to [first mates | second mates])
+    DevBuf orig;          // dy_shard_c1_unpack (paired): arrival index of every read (the batch is re-ordered to [first mates | second mates])
     bool pairLayout = false;
+    DevBuf fqText, fqRecs; u64 fqBytes = 0; bool fromFastq = false;     // dy_reads_from_fastq: the FASTQ window and its record table stay resident for dy_result_sam
 };
 
 struct dy_index
@@ -290,6 +294,7 @@ struct dy_index
     DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable, isa, ftext;
     bool hasIsa = false;
     bool hasFullSa = false, multiContig = false, sharded = false;
+    mutable DevBuf dNames, dNameOffs; mutable bool namesOnDevice = false;      // contig names for dy_result_sam (uploaded at the first use)
     std::vector<u64> ownedMask;     // bins whose FM structures are resident (all of them unless loaded sharded)
     DevBuf dOwnedMask;
     u32 prefixQ = 0;
@@ -1157,7 +1162,8 @@ void dy_reads_free(dy_reads * r)
     if (r->ctx->shBatch == r) r->ctx->shBatch = nullptr;
     if (r->ctx->pending.reads == r) { (void)hipStreamSynchronize(r->ctx->stream); r->ctx->pending.reads = nullptr; r->ctx->pending.f = nullptr; }     // chunks already queued write its masks
     for (auto & e : r->evK1) if (e) (void)hipEventDestroy(e);
-    if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); giveBuffer(r->ctx, r->orig); }
+    if (r->recycle) { giveBuffer(r->ctx, r->seqs); giveBuffer(r->ctx, r->seqsRc); giveBuffer(r->ctx, r->offs); giveBuffer(r->ctx, r->masks); giveBuffer(r->ctx, r->orig);
+                      giveBuffer(r->ctx, r->fqText); giveBuffer(r->ctx, r->fqRecs); }
     delete r;
 }
 
@@ -1455,7 +1461,7 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
         std::string d(dir);
         while (d.size() > 1 && d.back() == '/') d.pop_back();
         HostIndex H;
-        for (u32 b = 0; b < n_bins; ++b) appendBin(H, d + "/" + std::to_string(b), !owned || owned[b]);
+        loadHostIndex(H, d, n_bins, owned, std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
         std::unique_ptr<dy_index> idx(new dy_index);
         idx->ctx = ctx;
         idx->sharded = owned != nullptr;
@@ -1742,6 +1748,133 @@ int dy_map_get_stats(const dy_ctx * ctx, dy_map_stats * s)
     if (!ctx || !s) { g_lastError = "NULL argument"; return DY_EINVAL; }
     *s = ctx->stats;
     return DY_OK;
+}
+
+// ---- text in, text out (sam_kernels.h) ----------------------------------------------------------------------
+int dy_host_buffer(dy_ctx * ctx, uint32_t slot, uint64_t bytes, void ** out)
+{
+    return guarded([&] {
+        if (!ctx || !out) throw DyError(DY_EINVAL, "dy_host_buffer: NULL argument");
+        if (slot >= 8) throw DyError(DY_EINVAL, "dy_host_buffer: slots 0..7");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        ctx->hostSlots[slot].reserve((size_t)bytes + 64);
+        *out = ctx->hostSlots[slot].p;
+    });
+}
+
+uint64_t dy_reads_total_bases(const dy_reads * r) { return r ? r->totalBases : 0; }
+
+int dy_reads_from_fastq(dy_ctx * ctx, const void * text, uint64_t n_bytes, uint32_t max_reads, uint32_t at_eof, dy_reads ** out, uint64_t * consumed)
+{
+    return guarded([&] {
+        if (!ctx || !out || !consumed || (n_bytes && !text)) throw DyError(DY_EINVAL, "dy_reads_from_fastq: NULL argument");
+        if (max_reads == 0 || max_reads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
+        if (n_bytes >= 0xFFFFFF00ull) throw DyError(DY_EINVAL, "dy_reads_from_fastq: windows of 4 GiB or more are not supported");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        *consumed = 0;
+        std::unique_ptr<dy_reads> r(new dy_reads);
+        r->ctx = ctx; r->recycle = true; r->fromFastq = true; r->fqBytes = n_bytes;
+        takeBuffer(ctx, r->fqText, (size_t)n_bytes + 64);
+        if (n_bytes) HIP_CHECK(hipMemcpyAsync(r->fqText.p, text, (size_t)n_bytes, hipMemcpyHostToDevice, st));
+        // line ends of the window: count per 4 KB block, scan, write (only the first 4 x max_reads are kept)
+        const u32 nBlocks = (u32)((n_bytes + FQ_BLOCK_BYTES - 1) / FQ_BLOCK_BYTES);
+        const u32 cap = 4 * max_reads + 4;
+        ctx->fqBlockCount.reserve((size_t)(nBlocks + 1) * 4 + 64); ctx->fqBlockOff.reserve((size_t)(nBlocks + 1) * 4 + 64);
+        ctx->fqLineEnds.reserve((size_t)cap * 4 + 64); ctx->fqStatus.reserve(sizeof(FqStatus) + 64);
+        ctx->fqLensWide.reserve((size_t)(max_reads + 1) * 8 + 64); ctx->fqLens16.reserve((size_t)(max_reads + 1) * 2 + 64);
+        takeBuffer(ctx, r->fqRecs, (size_t)max_reads * sizeof(FqRec) + 64);
+        HIP_CHECK(hipMemsetAsync(ctx->fqBlockCount.as<u32>() + nBlocks, 0, 4, st));
+        if (nBlocks) hipLaunchKernelGGL(k_fq_count_lines, dim3(nBlocks), dim3(256), 0, st, r->fqText.as<u8>(), (u64)n_bytes, ctx->fqBlockCount.as<u32>());
+        exclusiveSum(ctx, ctx->fqBlockCount.as<u32>(), ctx->fqBlockOff.as<u32>(), (size_t)nBlocks + 1);
+        if (nBlocks) hipLaunchKernelGGL(k_fq_write_lines, dim3(nBlocks), dim3(256), 0, st, r->fqText.as<u8>(), (u64)n_bytes, ctx->fqBlockOff.as<u32>(), cap, ctx->fqLineEnds.as<u32>());
+        hipLaunchKernelGGL(k_fq_status, dim3(1), dim3(1), 0, st, ctx->fqBlockOff.as<u32>(), nBlocks, r->fqText.as<u8>(), (u64)n_bytes, at_eof ? 1u : 0u, max_reads, cap,
+                           ctx->fqLineEnds.as<u32>(), ctx->fqStatus.as<FqStatus>());
+        hipLaunchKernelGGL(k_fq_records, dim3((max_reads + 1 + 255) / 256), dim3(256), 0, st, r->fqText.as<u8>(), ctx->fqLineEnds.as<u32>(), ctx->fqStatus.as<FqStatus>(),
+                           r->fqRecs.as<FqRec>(), ctx->fqLensWide.as<u64>(), ctx->fqLens16.as<u16>());
+        HIP_CHECK(hipGetLastError());
+        // one fetch: the status and the read lengths (the host keeps them for MAPQ)
+        ctx->hostStatus.reserve(sizeof(FqStatus) + (size_t)max_reads * 2 + 64);
+        HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.p, ctx->fqStatus.p, sizeof(FqStatus), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.as<u8>() + sizeof(FqStatus), ctx->fqLens16.p, (size_t)max_reads * 2, hipMemcpyDeviceToHost, st));
+        fetchSync(ctx);
+        FqStatus fs; memcpy(&fs, ctx->hostStatus.p, sizeof(fs));
+        if (fs.bad)
+        {
+            std::string why;
+            if (fs.bad & 1) why += " a record does not start with '@';";
+            if (fs.bad & 2) why += " a separator line does not start with '+';";
+            if (fs.bad & 4) why += " an empty or over-long sequence line (or blank / wrapped lines);";
+            if (fs.bad & 8) why += " a quality line of another length than its sequence;";
+            if (fs.bad & 16) why += " carriage returns or blanks at line ends;";
+            if (fs.bad & 32) why += " an empty read name;";
+            dy_reads_free(r.release());
+            throw DyError(DY_EUNSUPPORTED, "dy_reads_from_fastq: not plain four-line FASTQ (" + why + " ) — parse this input on the host");
+        }
+        const u32 n = fs.nRecords;
+        r->n = n; r->totalBases = fs.totalBases; r->maxLen = n ? fs.maxLen : 0; r->minLen = n ? fs.minLen : 0;
+        r->lens->resize(n);
+        { const u16 * l16 = (const u16 *)(ctx->hostStatus.as<u8>() + sizeof(FqStatus)); u32 * lens = r->lens->data(); for (u32 i = 0; i < n; ++i) lens[i] = l16[i]; }
+        takeBuffer(ctx, r->seqs, r->totalBases + 64); takeBuffer(ctx, r->seqsRc, r->totalBases + 64);
+        takeBuffer(ctx, r->offs, (size_t)(n + 1) * 8);
+        exclusiveSum(ctx, ctx->fqLensWide.as<u64>(), r->offs.as<u64>(), (size_t)n + 1);
+        if (n) hipLaunchKernelGGL(k_fq_codes, dim3(std::min<u32>((n + 15) / 16, 65536u)), dim3(256), 0, st, r->fqText.as<u8>(), r->fqRecs.as<FqRec>(), n, r->offs.as<u64>(),
+                                  r->seqs.as<u8>(), r->seqsRc.as<u8>());
+        HIP_CHECK(hipGetLastError());
+        *consumed = fs.consumed;
+        *out = r.release();
+    });
+}
+
+int dy_result_sam(dy_result * res, const dy_reads * reads, const dy_index * idx, const char * read_group, uint32_t out_slot, const char ** text, uint64_t * n_bytes,
+                  uint64_t * n_mapped)
+{
+    return guarded([&] {
+        if (!res || !reads || !idx || !read_group || !text || !n_bytes) throw DyError(DY_EINVAL, "dy_result_sam: NULL argument");
+        if (out_slot >= 8) throw DyError(DY_EINVAL, "dy_result_sam: slots 0..7");
+        dy_ctx * ctx = res->ctx;
+        if (reads->ctx != ctx || idx->ctx != ctx) throw DyError(DY_EINVAL, "result, reads and index belong to different contexts");
+        if (!reads->fromFastq) throw DyError(DY_EINVAL, "dy_result_sam needs a batch of dy_reads_from_fastq (it copies names and qualities from the FASTQ text)");
+        if (res->nReads != reads->n) throw DyError(DY_EINVAL, "dy_result_sam: the result does not belong to these reads");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t st = ctx->stream;
+        const u32 n = reads->n;
+        *text = nullptr; *n_bytes = 0; if (n_mapped) *n_mapped = 0;
+        if (!n) return;
+        if (!idx->namesOnDevice)
+        {   // contig names of all bins, global ids (reference src/d_mapper.h:727-760 collects them for the header the same way)
+            std::vector<u8> chars; std::vector<u32> offs(idx->contigNames.size() + 1, 0);
+            for (size_t c = 0; c < idx->contigNames.size(); ++c) { chars.insert(chars.end(), idx->contigNames[c].begin(), idx->contigNames[c].end()); offs[c + 1] = (u32)chars.size(); }
+            upload(idx->dNames, chars); upload(idx->dNameOffs, offs);
+            idx->namesOnDevice = true;
+        }
+        const size_t rgLen = strlen(read_group);
+        ctx->samGroup.reserve(rgLen + 64);
+        if (rgLen) HIP_CHECK(hipMemcpyAsync(ctx->samGroup.p, read_group, rgLen, hipMemcpyHostToDevice, st));
+        ctx->samSizes.reserve((size_t)(n + 1) * 8 + 64); ctx->samOff.reserve((size_t)(n + 1) * 8 + 64); ctx->samMapq.reserve((size_t)n * 4 + 64); ctx->samFlags.reserve(64);
+        HIP_CHECK(hipMemsetAsync(ctx->samFlags.p, 0, 16, st));
+        SamArgs A;
+        A.text = reads->fqText.as<u8>(); A.recs = reads->fqRecs.as<FqRec>(); A.offs = reads->offs.as<u64>();
+        A.out = res->out.as<ReadOut>(); A.outSet = res->outSet.as<OutMatch>(); A.cigars = res->cigars.as<u32>();
+        A.contigNames = idx->dNames.as<u8>(); A.contigNameOffs = idx->dNameOffs.as<u32>();
+        A.readGroup = ctx->samGroup.as<u8>(); A.readGroupLen = (u32)rgLen; A.nReads = n;
+        hipLaunchKernelGGL(k_sam_sizes, dim3((n + 1 + 255) / 256), dim3(256), 0, st, A, ctx->samMapq.as<u32>(), ctx->samSizes.as<u64>(), ctx->samFlags.as<u32>(), ctx->samFlags.as<u32>() + 1);
+        exclusiveSum(ctx, ctx->samSizes.as<u64>(), ctx->samOff.as<u64>(), (size_t)n + 1);
+        ctx->hostStatus.reserve(64);
+        HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.p, ctx->samOff.as<u64>() + n, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.as<u8>() + 8, ctx->samFlags.p, 8, hipMemcpyDeviceToHost, st));
+        fetchSync(ctx);
+        u64 total; u32 flags[2];
+        memcpy(&total, ctx->hostStatus.p, 8); memcpy(flags, ctx->hostStatus.as<u8>() + 8, 8);
+        if (flags[0]) throw DyError(DY_EUNSUPPORTED, "dy_result_sam: a mapping quality lies on a rounding boundary of the device's arithmetic — format this batch on the host (dy_result_fetch)");
+        ctx->samText.reserve((size_t)total + 64);
+        hipLaunchKernelGGL(k_sam_write, dim3(std::min<u32>((n + 15) / 16, 65536u)), dim3(256), 0, st, A, ctx->samMapq.as<u32>(), ctx->samOff.as<u64>(), ctx->samText.as<u8>());
+        HIP_CHECK(hipGetLastError());
+        ctx->hostSlots[out_slot].reserve((size_t)total + 64);
+        HIP_CHECK(hipMemcpyAsync(ctx->hostSlots[out_slot].p, ctx->samText.p, (size_t)total, hipMemcpyDeviceToHost, st));
+        fetchSync(ctx);
+        *text = ctx->hostSlots[out_slot].as<char>(); *n_bytes = total; if (n_mapped) *n_mapped = flags[1];
+    });
 }
 
 // ---- bins sharded over ranks --------------------------------------------------------------------------

@@ -5,6 +5,8 @@
 #pragma once
 #include <string_view>
 #include <atomic>
+#include <cerrno>
+#include <chrono>
 #include "dy_types.h"
 #include <string>
 #include <vector>
@@ -49,13 +51,45 @@ public:
     size_t size() const { return size_; }
     // Maps the pages of [p, p + len) in one call (MADV_POPULATE_READ, Linux 5.14+; ignored where unknown): a first touch per 4 KB page
     // costs a sequential parser more than the parsing
-    void populate(const u8 * p, size_t len) const
+    // (the page-table work of a 200 MB window takes longer than parsing it with a dozen threads: the window is cut into slices, one call each)
+    void populate(const u8 * p, size_t len, unsigned threads = 1) const
     {
         if (!ptr_ || ptr_ == MAP_FAILED || !len || p < data() || p >= data() + size_) return;
         const size_t page = 4096;
         const size_t lo = (size_t)(p - data()) & ~(page - 1);
         size_t hi = (size_t)(p - data()) + len; if (hi > size_) hi = size_;
-        (void)madvise((u8 *)ptr_ + lo, hi - lo, 22 /* MADV_POPULATE_READ */);
+        const size_t nPages = (hi - lo + page - 1) / page;
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, nPages / 1024));
+        if (T <= 1) { (void)madvise((u8 *)ptr_ + lo, hi - lo, 22 /* MADV_POPULATE_READ */); return; }
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; ++t)
+        {
+            const size_t a = lo + nPages * t / T * page, b = std::min(hi, lo + nPages * (t + 1) / T * page);
+            if (b > a) pool.emplace_back([this, a, b] { (void)madvise((u8 *)ptr_ + a, b - a, 22 /* MADV_POPULATE_READ */); });
+        }
+        for (auto & th : pool) th.join();
+    }
+    // Copies file bytes [off, off + len) into dst with several threads (pread: page cache -> private memory, no page-table work)
+    bool readInto(u8 * dst, size_t off, size_t len, unsigned threads) const
+    {
+        if (fd_ < 0 || off + len > size_) return false;
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, len / ((size_t)4 << 20) + 1));
+        std::atomic<bool> ok(true);
+        auto part = [&](unsigned t) {
+            size_t lo = len * t / T; const size_t hi = len * (t + 1) / T;
+            while (lo < hi)
+            {
+                const ssize_t r = ::pread(fd_, dst + lo, hi - lo, (off_t)(off + lo));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) { ok = false; return; }
+                lo += (size_t)r;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto & th : pool) th.join();
+        return ok;
     }
 private:
     int fd_ = -1; void * ptr_ = nullptr; size_t size_ = 0;
@@ -79,7 +113,8 @@ struct HostIndex
 };
 
 // withFm = false: contigs and names only (a bin whose FM structures live on another rank), BinDesc::n stays 0
-inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = true)
+// One bin's 12 files -> a HostIndex of its own (offsets relative to this bin; merged by loadHostIndex).
+inline void parseBin(HostIndex & H, const std::string & prefix, bool withFm = true)
 {
     BinDesc d; memset(&d, 0, sizeof(d));
     MappedFile size(prefix + ".txt.size");
@@ -89,7 +124,7 @@ inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = t
     if (nContigs == 0) throw IoError("Error while opening reference file.");
     if (nContigs > 65535) throw IoError("Maximum number of contigs exceeded. Recompile with -DDR_YARA_LARGE_CONTIGS=ON. (" + prefix + ")");
     d.nContigs = (u32)nContigs;
-    d.contigIdBase = (u32)H.contigNames.size();
+    d.contigIdBase = 0;
 
     // contigs: txt.limits (u64 prefix sums) + txt.concat (word 0 = length, then 21 bases / u64, 3 bit each, MSB first)
     {
@@ -187,6 +222,72 @@ inline void appendBin(HostIndex & H, const std::string & prefix, bool withFm = t
         }
     }
     H.bins.push_back(d);
+}
+
+// All bins of an index directory, parsed by several threads (a bin's files are independent: unpacking 3-bit contigs and splitting the
+// packed SA samples of 64 x 4 Mbp takes 0.4 s on one thread), then laid out back to back exactly like the device arena.
+inline void loadHostIndex(HostIndex & H, const std::string & dir, u32 nBins, const uint8_t * owned, unsigned threads)
+{
+    std::vector<HostIndex> parts(nBins);
+    std::vector<std::string> errors(nBins);
+    std::atomic<u32> next(0);
+    auto work = [&] {
+        for (;;)
+        {
+            const u32 b = next.fetch_add(1);
+            if (b >= nBins) break;
+            try { parseBin(parts[b], dir + "/" + std::to_string(b), !owned || owned[b]); }
+            catch (std::exception const & e) { errors[b] = e.what(); if (errors[b].empty()) errors[b] = "error"; }
+        }
+    };
+    const unsigned T = std::max(1u, std::min<unsigned>(threads, nBins));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto & th : pool) th.join();
+    for (u32 b = 0; b < nBins; ++b) if (!errors[b].empty()) throw IoError(errors[b]);
+    // offsets of every bin in the merged arrays
+    struct Off { size_t rank, ind, val, contigs, limits, drp, names; };
+    std::vector<Off> off(nBins + 1);
+    Off acc = {0, 0, 0, 0, 0, 0, 0};
+    for (u32 b = 0; b < nBins; ++b)
+    {
+        off[b] = acc;
+        const HostIndex & P = parts[b];
+        acc.rank += P.rank.size(); acc.ind += P.ind.size(); acc.val += P.valOffset.size(); acc.contigs += P.contigs.size();
+        acc.limits += P.limits.size(); acc.drp += P.drp.size(); acc.names += P.contigNames.size();
+    }
+    off[nBins] = acc;
+    if (acc.limits > 0xFFFFFFFFull || acc.drp > 0xFFFFFFFFull || acc.names > 0xFFFFFFFFull) throw IoError("too many contigs in the index");
+    H.rank.resize(acc.rank); H.ind.resize(acc.ind); H.valOffset.resize(acc.val); H.valContig.resize(acc.val); H.contigs.resize(acc.contigs);
+    H.limits.resize(acc.limits); H.drp.resize(acc.drp); H.contigNames.resize(acc.names); H.contigLengths.resize(acc.names);
+    H.bins.resize(nBins);
+    next = 0;
+    auto place = [&] {
+        for (;;)
+        {
+            const u32 b = next.fetch_add(1);
+            if (b >= nBins) break;
+            HostIndex & P = parts[b];
+            const Off & o = off[b];
+            BinDesc d = P.bins[0];
+            d.rankOff = o.rank / 32; d.indOff = o.ind / 8; d.valOff = o.val; d.contigOff = o.contigs; d.limOff = (u32)o.limits; d.drpOff = (u32)o.drp;
+            d.contigIdBase = (u32)o.names;
+            H.bins[b] = d;
+            if (!P.rank.empty()) memcpy(H.rank.data() + o.rank, P.rank.data(), P.rank.size());
+            if (!P.ind.empty()) memcpy(H.ind.data() + o.ind, P.ind.data(), P.ind.size());
+            if (!P.valOffset.empty()) { memcpy(H.valOffset.data() + o.val, P.valOffset.data(), P.valOffset.size() * 4); memcpy(H.valContig.data() + o.val, P.valContig.data(), P.valContig.size() * 2); }
+            if (!P.contigs.empty()) memcpy(H.contigs.data() + o.contigs, P.contigs.data(), P.contigs.size());
+            std::copy(P.limits.begin(), P.limits.end(), H.limits.begin() + o.limits);
+            std::copy(P.drp.begin(), P.drp.end(), H.drp.begin() + o.drp);
+            for (size_t i = 0; i < P.contigNames.size(); ++i) { H.contigNames[o.names + i] = std::move(P.contigNames[i]); H.contigLengths[o.names + i] = P.contigLengths[i]; }
+            P = HostIndex();
+        }
+    };
+    pool.clear();
+    for (unsigned t = 1; t < T; ++t) pool.emplace_back(place);
+    place();
+    for (auto & th : pool) th.join();
 }
 
 // .filter file = sdsl::bit_vector: u64 bit count, then ceil(bits/64) words.
@@ -289,14 +390,21 @@ public:
     size_t next(ReadsBatch & b, size_t maxReads, unsigned threads = 1)
     {
         b.clear();
-        spans_.clear();
+        nSpans_ = 0;                                   // (spans_ keeps its storage: re-creating a million spans would zero-fill 64 MB per batch)
         skipBlank();
         if (p_ >= end_ || maxReads == 0) { b.nameChars.clear(); b.codes.clear(); b.quals.clear(); return 0; }
         if (*p_ != '>' && *p_ != '@') throw IoError("unrecognised reads file format");
-        map_.populate(p_, bytesPerRecord_ > 0 ? (size_t)(bytesPerRecord_ * (double)maxReads * 1.05) + 65536 : (size_t)64 << 20);
+        auto tick = [] { return std::chrono::steady_clock::now(); };
+        auto lap = [&](double & acc, std::chrono::steady_clock::time_point & t) { const auto n = tick(); acc += std::chrono::duration<double>(n - t).count(); t = n; };
+        auto tp = tick();
+        const bool threaded = threads > 1 && *p_ == '@' && bytesPerRecord_ > 0;
+        if (!(threaded && copyWindow && inflated_.empty()))
+            map_.populate(p_, bytesPerRecord_ > 0 ? (size_t)(bytesPerRecord_ * (double)maxReads * 1.05) + 65536 : (size_t)64 << 20, threads);
+        lap(phase[0], tp);
         if (!(threads > 1 && *p_ == '@' && bytesPerRecord_ > 0 && indexFastqWindow(maxReads, threads)))
         {
             const u8 * first = p_;
+            spans_.clear();
             while (spans_.size() < maxReads)
             {
                 skipBlank();
@@ -325,13 +433,38 @@ public:
                 spans_.push_back(r);
             }
             if (!spans_.empty()) bytesPerRecord_ = (double)(p_ - first) / (double)spans_.size();
+            nSpans_ = spans_.size();
         }
-        const size_t n = spans_.size();
+        lap(phase[1], tp);
+        const size_t n = nSpans_;
         b.offs.resize(n + 1); b.nameOffs.resize(n + 1);
         u64 bases = 0, nameBytes = 0;
-        for (size_t i = 0; i < n; ++i) { b.offs[i] = bases; b.nameOffs[i] = nameBytes; bases += spans_[i].len; nameBytes += (u64)(spans_[i].nameE - spans_[i].nameS); }
+        {   // offsets of the reads and of their names: per-thread partial sums, then every thread fills its range
+            const unsigned TP = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 65536 + 1));
+            std::vector<u64> pb(TP + 1, 0), pn(TP + 1, 0);
+            auto sums = [&](unsigned t) {
+                u64 sb = 0, sn = 0;
+                for (size_t i = n * t / TP; i < n * (t + 1) / TP; ++i) { sb += spans_[i].len; sn += (u64)(spans_[i].nameE - spans_[i].nameS); }
+                pb[t + 1] = sb; pn[t + 1] = sn;
+            };
+            auto fill = [&](unsigned t) {
+                u64 sb = pb[t], sn = pn[t];
+                for (size_t i = n * t / TP; i < n * (t + 1) / TP; ++i) { b.offs[i] = sb; b.nameOffs[i] = sn; sb += spans_[i].len; sn += (u64)(spans_[i].nameE - spans_[i].nameS); }
+            };
+            auto runAll = [&](auto && f) {
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < TP; ++t) pool.emplace_back(f, t);
+                f(0u);
+                for (auto & th : pool) th.join();
+            };
+            runAll(sums);
+            for (unsigned t = 0; t < TP; ++t) { pb[t + 1] += pb[t]; pn[t + 1] += pn[t]; }
+            runAll(fill);
+            bases = pb[TP]; nameBytes = pn[TP];
+        }
         b.offs[n] = bases; b.nameOffs[n] = nameBytes;
         b.nameChars.resize(nameBytes); b.codes.resize(bases); b.quals.resize(bases);
+        lap(phase[2], tp);
         auto convert = [&](size_t lo, size_t hi) {
             static const Dna5Table lut;
             for (size_t i = lo; i < hi; ++i)
@@ -376,8 +509,17 @@ public:
             convert(0, n / T);
             for (auto & th : pool) th.join();
         }
+        lap(phase[3], tp);
         return n;
     }
+    bool copyWindow = false;           // true: parse a private copy of each window made by parallel preads (measured: no gain)
+    // for the device-side parser (dy_reads_from_fastq): is this an uncompressed file that starts like FASTQ, its size, raw reads, and where the
+    // host parser would continue
+    bool plainFastq() const { return inflated_.empty() && map_.size() > 0 && map_.data()[0] == '@'; }
+    size_t fileSize() const { return map_.size(); }
+    bool readRaw(u8 * dst, size_t off, size_t len, unsigned threads) const { return map_.readInto(dst, off, len, threads); }
+    void seek(size_t off) { p_ = map_.data() + std::min(off, map_.size()); }
+    double phase[4] = {0, 0, 0, 0};    // seconds spent in: page population, record boundaries, offsets + allocation, conversion (observability: -v)
 private:
     struct Dna5Table { u8 code[256]; Dna5Table() { for (int c = 0; c < 256; ++c) code[c] = dna5Code((char)c); } };
     struct RecSpan { const u8 * nameS, * nameE, * seqS, * seqE, * qualS, * qualE; size_t len; bool fasta; };
@@ -405,13 +547,23 @@ private:
     {
         const size_t remaining = (size_t)(end_ - p_);
         const u8 * base = p_;
+        if (copyWindow && inflated_.empty())
+        {   // the window as a private copy made by several threads: touching the mapped file's pages for the first time (one fault per 4 KB,
+            // or one populate call) competes with the page-cache work of the output writer, a parallel pread does not
+            if (window_.size() < window + 64) window_.resize(window + window / 8 + 64);
+            if (map_.readInto(window_.data(), (size_t)(p_ - map_.data()), window, threads)) base = window_.data();
+        }
+        const u8 * const origin = p_;
         // line ends of the window, chunk by chunk
         const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, window / (1 << 20) + 1));
-        std::vector<std::vector<u32> > ends(T);
+        if (ends_.size() < T) ends_.resize(T);                     // kept across batches: no allocation, no first touch of fresh pages per batch
+        std::vector<std::vector<u32> > & ends = ends_;
+        for (unsigned t = T; t < ends.size(); ++t) ends[t].clear();
         if (window > 0xFFFFFFF0ull) return false;
         auto scan = [&](unsigned t) {
             const size_t lo = window * t / T, hi = window * (t + 1) / T;
             std::vector<u32> & v = ends[t];
+            v.clear();
             v.reserve((hi - lo) / 48 + 16);
             const u8 * q = base + lo, * stop = base + hi;
             while (q < stop)
@@ -436,13 +588,24 @@ private:
         if (nRec > maxReads) nRec = maxReads;
         if (nRec == 0 || (nRec < maxReads && !atEof)) return false;                 // the window came out too small: general path
         lineEnds_.resize(nRec * 4);
-        {
-            size_t at = 0;
-            for (auto & v : ends) for (u32 e : v) { if (at == nRec * 4) break; lineEnds_[at++] = e; }
-            if (at < nRec * 4) lineEnds_[at++] = (u32)window;                        // the unterminated last line
-            if (at < nRec * 4) return false;
+        {   // every scanner copies its own line ends into place
+            std::vector<size_t> start(T + 1, 0);
+            for (unsigned t = 0; t < T; ++t) start[t + 1] = start[t] + ends[t].size();
+            const size_t want = nRec * 4;
+            auto place = [&](unsigned t) {
+                if (start[t] >= want) return;
+                const size_t n = std::min(ends[t].size(), want - start[t]);
+                if (n) memcpy(lineEnds_.data() + start[t], ends[t].data(), n * sizeof(u32));
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; ++t) pool.emplace_back(place, t);
+            place(0);
+            for (auto & th : pool) th.join();
+            size_t at = std::min(start[T], want);
+            if (at < want) lineEnds_[at++] = (u32)window;                            // the unterminated last line
+            if (at < want) return false;
         }
-        spans_.resize(nRec);
+        if (spans_.size() < nRec) spans_.resize(nRec);
         std::atomic<bool> ok(true);
         auto build = [&](size_t lo, size_t hi) {
             for (size_t r = lo; r < hi; ++r)
@@ -467,14 +630,18 @@ private:
             build(0, nRec / TB);
             for (auto & th : pool) th.join();
         }
-        if (!ok) { spans_.clear(); return false; }
+        if (!ok) return false;
         const size_t used = (size_t)lineEnds_[nRec * 4 - 1] + 1;
-        p_ = base + (used < window ? used : window);
-        bytesPerRecord_ = (double)(p_ - base) / (double)nRec;
+        p_ = origin + (used < window ? used : window);
+        bytesPerRecord_ = (double)(p_ - origin) / (double)nRec;
+        nSpans_ = nRec;
         return true;
     }
     std::vector<RecSpan> spans_;
+    size_t nSpans_ = 0;                // records of the current batch in spans_
     std::vector<u32> lineEnds_;
+    std::vector<std::vector<u32> > ends_;
+    std::vector<u8> window_;           // private copy of the window being parsed (copyWindow)
     double bytesPerRecord_ = 0;        // of the previous batch: sizes the window of the threaded FASTQ path
     MappedFile map_;
     std::vector<u8> inflated_;

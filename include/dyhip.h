@@ -225,6 +225,28 @@ typedef struct {
 } dy_map_stats;
 int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
 
+/* ---- text in, text out: FASTQ -> reads and results -> SAM on the device ------------------------------------------
+ * The host share of a GPU box is a few cores: parsing FASTQ (215 B per 100-bp read) and formatting SAM (275 B) cost them more time
+ * than the mapping costs the device.  With these entry points the host only moves bytes — file -> pinned buffer -> device ->
+ * pinned buffer -> file — and the records are byte-identical to the host path's. */
+/* Pinned host memory owned by the context (slots 0..7, grow-only): read a file straight into it / write a file straight out of it. */
+int  dy_host_buffer(dy_ctx *ctx, uint32_t slot, uint64_t bytes, void **out);
+/* readRecords of a four-line FASTQ file — reference src/mapper.h:445-469 (loadReads; SeqAn SeqFileIn): `text` holds the next bytes of the
+ * file (host memory, best a dy_host_buffer), at_eof != 0 if they reach its end.  The batch takes the first max_reads records (all
+ * complete ones if the window holds fewer: the caller retries with a larger window unless at_eof); *consumed = the bytes they occupy.
+ * Dna5 codes, qualities (clamped to 6 bits, '!' under N) and names (cut at the first blank, tab or '/') as the reference stores them.
+ * DY_EUNSUPPORTED (with the reason) for anything but plain four-line records — blank lines, CR line ends, wrapped sequences, FASTA:
+ * parse such input on the host and use dy_reads_upload. */
+int  dy_reads_from_fastq(dy_ctx *ctx, const void *text, uint64_t n_bytes, uint32_t max_reads, uint32_t at_eof, dy_reads **out, uint64_t *consumed);
+uint64_t dy_reads_total_bases(const dy_reads *r);
+/* MatchesWriter for single-end reads — reference src/mapper_writer.h:176-225 (tags NM X0 X1 RG XA, MAPQ), :296-345 (record), :593-634 (XA):
+ * the SAM records of a batch of dy_reads_from_fastq, in read order, formatted on the device from the results left by
+ * dy_map_reads_async (no dy_result_fetch needed) and copied into the context's pinned slot `out_slot`; *text stays valid until the
+ * slot is used again.  DY_EUNSUPPORTED if a mapping quality lies on a rounding boundary of the device's arithmetic (then format the
+ * batch on the host from dy_result_fetch).  Paired-end and BAM records are formatted by the caller. */
+int  dy_result_sam(dy_result *r, const dy_reads *reads, const dy_index *idx, const char *read_group, uint32_t out_slot, const char **text, uint64_t *n_bytes,
+                   uint64_t *n_mapped);
+
 /* ---- bins sharded over ranks (one process or host thread per GPU) -----------------------------------------
  * The reference's unit of distribution is the bin (src/d_mapper.h:876-884: one child Mapper per bin; copyMatches
  * :127-155, copyCigars :186-215 and finalizeMainMapper :828-838 merge per read).  With G ranks every rank holds the filter,

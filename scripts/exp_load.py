@@ -1,21 +1,25 @@
-"""Load times of the bench filter and index (what the CLI pays before the first batch)."""
+"""Where the tool's loading time goes: context creation, filter file -> device, index files -> device (host parse + device-side tables)."""
 import os, sys, time
-import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import dream_yara_amd as dy
+import torch  # noqa: F401
 import bench
-wl = bench.WORKLOADS["config2"]
-work = "/tmp/dy_bench_%d/config2" % os.getuid(); os.makedirs(work, exist_ok=True)
-genomes, idx_dir = bench.build_inputs(wl, work, 0, 1, lambda: None)
-fpath = os.path.join(work, "cli.filter")
-ctx = dy.Context(0)
-if not os.path.exists(fpath):
-    ibf = dy.Ibf.create(ctx, wl["bins"], wl["h"], wl["k"], (1 << 33) + 256)
-    for b, g in enumerate(genomes): ibf.add(g, b)
-    ibf.save(fpath); ibf.close()
-for it in range(3):
-    t0 = time.perf_counter(); ibf = dy.Ibf.load(ctx, fpath); ctx.sync(); t1 = time.perf_counter()
-    idx = dy.Index(ctx, idx_dir, wl["bins"]); ctx.sync(); t2 = time.perf_counter()
-    print("filter load %.3f s, index load %.3f s" % (t1 - t0, t2 - t1), flush=True)
-    ibf.close(); idx.close()
+from dream_yara_amd.dist import Group
+import dream_yara_amd as dy
+class A: pass
+args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"
+s = bench.Setup(sys.argv[1] if len(sys.argv) > 1 else "config2", args, Group(None))
+fpath = os.path.join(s.work_dir, "cli.filter"); s.ibf.save(fpath)
+idx_dir, bins = s.idx_dir, s.wl["bins"]
+s.close()
+for rep in range(2):
+    t0 = time.time(); ctx = dy.Context(0); t1 = time.time()
+    ibf = dy.Ibf.load(ctx, fpath); t2 = time.time()
+    idx = dy.Index(ctx, idx_dir, bins); t3 = time.time()
+    for k, v in (("sparse_sa", 1), ("prefix_q", 0)):
+        pass
+    print("ctx %.3f s, filter %.3f s, index %.3f s" % (t1 - t0, t2 - t1, t3 - t2), flush=True)
+    idx.close(); ibf.close(); ctx.close()
+ctx = dy.Context(0); ctx.set_tuning("sparse_sa", 1); ctx.set_tuning("prefix_q", 0); ctx.set_tuning("no_isa", 1)
+t0 = time.time(); idx = dy.Index(ctx, idx_dir, bins); print("index without device-only tables %.3f s" % (time.time() - t0))
+os.remove(fpath)

@@ -49,7 +49,8 @@ int main(int argc, char ** argv)
                 sum += b.offs.back() * 31 + b.name(b.size() - 1).size() + b.codes[b.codes.size() / 2] + (u64)b.quals[b.quals.size() / 3];
             }
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            std::cout << reads << " reads in " << dt << " s = " << reads / dt / 1e6 << " M reads/s, checksum " << sum << "\n";
+            std::cout << reads << " reads in " << dt << " s = " << reads / dt / 1e6 << " M reads/s, checksum " << sum
+                      << " | populate " << in.phase[0] << " boundaries " << in.phase[1] << " offsets+alloc " << in.phase[2] << " convert " << in.phase[3] << "\n";
             return 0;
         }
         if (mode == "write" && argc == 6)

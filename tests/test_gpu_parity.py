@@ -320,6 +320,92 @@ def test_map_matches_oracle_on_gold_data(dy, ctx, ob, small_filter, strata):
     oidx.close(); oibf.close()
 
 
+def _gold_reads_as_fastq(rng, n=None):
+    """The gold reads as four-line FASTQ with what a parser has to normalise: names with comments and /1 suffixes, lower-case bases, IUPAC
+    codes and Ns, qualities up to '~' (clamped to 6 bits by Dna5Q) and under Ns."""
+    names, codes, offs = read_fasta_codes(READS_FA)
+    n = n or len(names)
+    recs = []
+    for i in range(n):
+        seq = bytearray(np.frombuffer(b"ACGTN", np.uint8)[codes[int(offs[i]):int(offs[i + 1])]].tobytes())
+        qual = bytearray(rng.integers(33, 127, len(seq), dtype=np.uint8).tobytes())
+        if i % 7 == 0:
+            seq = bytearray(bytes(seq).lower())
+        if i % 11 == 0:
+            seq[int(rng.integers(0, len(seq)))] = ord("R")            # IUPAC code: stored as N
+        name = names[i] + ("/1" if i % 3 == 0 else "") + (" a comment" if i % 5 == 0 else "") + ("\twith a tab" if i % 13 == 0 else "")
+        recs.append(b"@" + name.encode() + b"\n" + bytes(seq) + b"\n+" + (name.encode() if i % 17 == 0 else b"") + b"\n" + bytes(qual) + b"\n")
+    return recs
+
+
+def test_device_fastq_parse_and_sam_format_equal_the_host_path(product_build, dy, ob, small_filter, tmp_path):
+    """dy_reads_from_fastq + dy_result_sam (FASTQ text in, SAM text out, both on the device) against the tool's host path (ReadsFile parser +
+    samWriteRecord) on the same file: byte-identical records; the batch itself (codes, lengths) equals the host parser's."""
+    rng = np.random.default_rng(11)
+    recs = _gold_reads_as_fastq(rng)
+    text = b"".join(recs)
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(text)
+    exe = os.path.join(product_build, "dream_yara_mapper")
+    host_sam = str(tmp_path / "host.sam")
+    subprocess.check_call([exe, "-fi", small_filter, GOLD_INDEX + "/", str(fq), "-o", host_sam, "-e", "3", "-s", "10", "-rb", "1000", "--host-io"])
+    want = [l for l in open(host_sam, "rb").read().split(b"\n") if l and not l.startswith(b"@")]
+    c = dy.Context(0)
+    try:
+        idx = dy.Index(c, GOLD_INDEX, 64)
+        ibf = dy.Ibf.load(c, small_filter)
+        er = np.float32(0.03)
+        params = dy.default_params(error_rate=er, strata_rate=np.float32(0.10))
+        got, at, sizes = [], 0, []
+        while at < len(text):
+            window = text[at: at + 300_000]                              # about 1 300 records; the batch takes 1 000 of them
+            reads, used = dy.Reads.from_fastq(c, window, 1000, at_eof=at + len(window) >= len(text))
+            assert used > 0 and reads.n == min(1000, len(recs) - len(sizes) * 1000 if False else reads.n)
+            avg = reads.total_bases() * 2 // (reads.n * 2)
+            ibf.query(reads, dy.threshold(er, 19, avg), want_masks=False)
+            res = dy.map_reads(c, idx, reads, params, asynchronous=True)
+            sam, n_mapped = res.sam(reads, idx, "none")
+            got += [l for l in sam.split(b"\n") if l]
+            sizes.append(reads.n)
+            res.close(); reads.close()
+            at += used
+        assert sizes == [1000] * 6 + [400]
+        assert len(got) == len(want) == 6400
+        bad = [i for i in range(6400) if got[i] != want[i]]
+        assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
+        # the tool takes the device path by itself for such input: the same file, and also with a first window too small for a batch (long
+        # comments: the window is read again, larger), and with CR line ends (the device parser refuses, the host parser takes over)
+        dev_sam = str(tmp_path / "dev.sam")
+        subprocess.check_call([exe, "-fi", small_filter, GOLD_INDEX + "/", str(fq), "-o", dev_sam, "-e", "3", "-s", "10", "-rb", "1000"])
+        assert [l for l in open(dev_sam, "rb").read().split(b"\n") if l and not l.startswith(b"@")] == want
+        for tag, variant in (("long", b"".join(r.replace(b"\n", b" " + b"x" * 420 + b"\n", 1) for r in recs)), ("crlf", text.replace(b"\n", b"\r\n"))):
+            f2 = tmp_path / (tag + ".fq")
+            f2.write_bytes(variant)
+            outs = []
+            for extra in ([], ["--host-io"]):
+                o = str(tmp_path / (tag + "".join(extra) + ".sam"))
+                subprocess.check_call([exe, "-fi", small_filter, GOLD_INDEX + "/", str(f2), "-o", o, "-e", "3", "-s", "10", "-rb", "1000", "-sk"] + extra)
+                outs.append(open(o, "rb").read())
+            assert outs[0] == outs[1] and outs[0].count(b"\n") == 6400, tag                 # -sk: no header lines
+        # the last line without its newline, and a window that ends inside a record
+        reads, used = dy.Reads.from_fastq(c, text[:-1], 7000, at_eof=True)
+        assert reads.n == 6400 and used == len(text) - 1
+        reads.close()
+        cut = len(b"".join(recs[:10])) + 30
+        reads, used = dy.Reads.from_fastq(c, text[:cut], 1000, at_eof=False)
+        assert reads.n == 10 and used == cut - 30
+        reads.close()
+        # what the device parser leaves to the host: CR line ends, blank lines, FASTA, wrapped sequences, a short quality line
+        for badtext in (text[:5000].replace(b"\n", b"\r\n"), recs[0] + b"\n" + recs[1], open(READS_FA, "rb").read()[:4000],
+                        recs[0][:60] + b"\n" + recs[0][60:], recs[0][:-5] + b"\n"):
+            with pytest.raises(dy.DyError) as e:
+                dy.Reads.from_fastq(c, badtext, 1000, at_eof=True)
+            assert e.value.code == -6 and "four-line FASTQ" in str(e.value)
+        ibf.close(); idx.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("chunk", [1024, 16384])
 def test_deferred_sweep_gives_the_same_masks_and_results(dy, ob, small_filter, chunk):
     """dy_ibf_query_deferred: the sweep of the batch mapped next is queued chunk by chunk in front of the host's waits of the current
