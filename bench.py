@@ -113,6 +113,23 @@ def cpu_model():
     return "unknown"
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the cgroup's quota (a GPU box gives a 16-CPU share of its 256 logical cores) or the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def compare_all_fields(dev, ora):
     """Every field of every read: per-read records, primary match bytes, matchesSet bytes, CIGAR ops.  Returns the differing fields."""
     d_reads, d_matches, d_cigars = dev
@@ -476,7 +493,7 @@ def measure_end_to_end(s, n_reads, ob_sample):
         fq_s = os.path.join(s.work_dir, "cli_sample.fq")
         with open(fq_s, "wb") as f:
             f.write(blob[: ob_sample * (14 + 2 * L)])
-        threads = min(os.cpu_count() or 1, 64)
+        threads = min(effective_cpus(), 64)
         oexe = os.path.join(ROOT, "oracle", "_build", "oracle_mapper")
         dt_o, load_o = timed([oexe, "-fi", fpath, s.idx_dir, fq_s, "-o", out_sam, "-e", str(wl["e"]), "-t", str(threads), "-v"])
         res["cpu"] = {"value": ob_sample / dt_o, "unit": "reads/s", "reads": ob_sample, "seconds": dt_o, "load_seconds": load_o, "cores": threads, "kind": "port",
@@ -503,7 +520,7 @@ def main():
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="N = 1: also measure the other geometries, the bins-sharded partitioning through RCCL, the PCIe-inclusive and the end-to-end rates (auto = with the default workload)")
     ap.add_argument("--extras-budget", type=float, default=420.0, help="seconds of wall clock after which no further extra measurement is started")
-    ap.add_argument("--e2e-reads", type=int, default=16_000_000)
+    ap.add_argument("--e2e-reads", type=int, default=32_000_000)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dy_ctx_set_tuning knob for experiments (result-identical code paths; see include/dyhip.h)")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
@@ -582,9 +599,9 @@ def main():
     if rank == 0 and args.cpu_sample > 0 and legs[0] == "reads":
         # CPU baseline: the oracle (kind "port") on a bounded sample of the same batch; the sample doubles as the parity check of the timed configuration
         sample = args.cpu_sample if world == 1 else min(args.cpu_sample, 200000)
-        threads = min(os.cpu_count() or 1, 64)
+        threads = min(effective_cpus(), 64)
         p = s.parity(result, sample, threads, ob, time_single=200000 if world == 1 else 0)
-        base = {"value": p["n"] / p["seconds"], "unit": "reads/s", "cores": threads, "host_cores": os.cpu_count() or 1, "host_cpu": cpu_model(), "kind": "port",
+        base = {"value": p["n"] / p["seconds"], "unit": "reads/s", "cores": threads, "host_cores": os.cpu_count() or 1, "host_cpu_quota": effective_cpus(), "host_cpu": cpu_model(), "kind": "port",
                 "sample": "%d reads of the same batch, oracle (oracle/dyo_*.hpp: a restatement of the reference, not the SeqAn binary) with %d threads, %.1f s" % (p["n"], threads, p["seconds"]),
                 "region": "map_batch on arrays resident in host memory: filter/index load, FASTQ parsing and SAM writing excluded (end_to_end.cpu times the command line)",
                 "mapped_fraction": p["mapped_fraction"], "single_thread": p["single_thread"], "parity_with_gpu_on_sample": not p["differs_in"],
@@ -637,7 +654,7 @@ def main():
                 w = Setup(name, args, grp)
                 leg_w, res_w = w.run_leg("reads", steps_w, 1)
                 roof = w.roofline(leg_w)
-                p = w.parity(res_w, 200000, min(os.cpu_count() or 1, 64), ob)
+                p = w.parity(res_w, 200000, min(effective_cpus(), 64), ob)
                 line["workloads"][name] = {
                     "workload": w.wl["desc"], "value": leg_w["value"], "unit": "reads/s", "ms_per_step": leg_w["ms_per_step"], "steps": steps_w, "warmup": 1,
                     "resident_batches": w.n_batches, "stage_ms_per_step": leg_w["stage_ms_per_step"],

@@ -589,7 +589,14 @@ int main(int argc, char ** argv)
             size_t pos = 0; bool fellBack = false; std::string failure;
             try
             {
+                // first window: sized from the record length seen in the first 256 KB of the file
                 size_t window = std::min<size_t>(fileSize, (size_t)opt.readsBatch * 512 + 65536);
+                {
+                    std::vector<u8> probe(std::min<size_t>(fileSize, (size_t)256 << 10));
+                    size_t lines = 0;
+                    if (!probe.empty() && in.readRaw(probe.data(), 0, probe.size(), 1)) for (u8 c : probe) lines += c == '\n';
+                    if (lines >= 8) window = std::min<size_t>(fileSize, (size_t)((double)probe.size() / (double)(lines / 4) * opt.readsBatch * 1.05) + 65536);
+                }
                 request(0, window);
                 int k = 0;
                 for (int j = 0; pos < fileSize; ++j)

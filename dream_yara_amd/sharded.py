@@ -226,5 +226,12 @@ class ShardedMapper:
         return res
 
     def close(self):
+        # torch's caching allocator ties the blocks it handed out under the context's stream to that stream (and records events on it): they
+        # go back to the driver here, while the stream still exists — the caller destroys it with the context
         self._keep = []
+        self.hdr = self.rows = self.pinned = None
+        if self.stream is not None:
+            self.stream.synchronize()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
         self.index.close()
