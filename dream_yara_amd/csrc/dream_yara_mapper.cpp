@@ -567,15 +567,16 @@ int main(int argc, char ** argv)
                 }
                 catch (std::exception const & e) { std::lock_guard<std::mutex> lk(m); readerError = e.what(); cv.notify_all(); }
             });
-            // writer: the SAM text of batch k lies in pinned slot 2 + (k & 1)
-            const char * outText[2] = {nullptr, nullptr}; uint64_t outBytes[2] = {0, 0}; int produced = 0, written = 0;
+            // writer: the SAM text of batch k lies in pinned slot 2 + k % 3 (three slots: the writer — the slowest stage, one thread copying into the
+            // page cache — then runs back to back while the device works up to two batches ahead)
+            const char * outText[3] = {nullptr, nullptr, nullptr}; uint64_t outBytes[3] = {0, 0, 0}; int produced = 0, written = 0;
             std::thread writerThread([&] {
                 try
                 {
                     for (int k = 0;; ++k)
                     {
                         const char * t; uint64_t n;
-                        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return produced > k || stop; }); if (produced <= k) return; t = outText[k & 1]; n = outBytes[k & 1]; }
+                        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return produced > k || stop; }); if (produced <= k) return; t = outText[k % 3]; n = outBytes[k % 3]; }
                         const auto w0 = now();
                         if (samFd >= 0) { writeAll(samFd, t, (size_t)n, samOffset); samOffset += n; }
                         else os.write(t, (std::streamsize)n);
@@ -636,16 +637,16 @@ int main(int argc, char ** argv)
                     int rm = dy_map_reads_async(D.ctx, D.idx, reads, &opt.params, &res);
                     if (rm != DY_OK) { dy_reads_free(reads); check(rm); }
                     ioMap += since(d0); d0 = now();
-                    { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return written >= k - 1 || !writerError.empty(); }); if (!writerError.empty()) fail(writerError); }   // slot of batch k - 2 is free
+                    { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return written >= k - 2 || !writerError.empty(); }); if (!writerError.empty()) fail(writerError); }   // slot of batch k - 3 is free
                     ioWaitWrite += since(d0); d0 = now();
                     const char * text = nullptr; uint64_t nBytes = 0, nMapped = 0;
-                    const int rs = dy_result_sam(res, reads, D.idx, opt.readGroup.c_str(), (uint32_t)(2 + (k & 1)), &text, &nBytes, &nMapped);
+                    const int rs = dy_result_sam(res, reads, D.idx, opt.readGroup.c_str(), (uint32_t)(2 + k % 3), &text, &nBytes, &nMapped);
                     dy_result_free(res); dy_reads_free(reads);
                     if (rs == DY_EUNSUPPORTED) { pos -= consumed; fellBack = true; break; }           // (a mapping quality on a rounding boundary: the host formats from here on)
                     check(rs);
                     total += n; mapped += nMapped;
                     ioFormat += since(d0);
-                    { std::lock_guard<std::mutex> lk(m); outText[k & 1] = text; outBytes[k & 1] = nBytes; produced = k + 1; }
+                    { std::lock_guard<std::mutex> lk(m); outText[k % 3] = text; outBytes[k % 3] = nBytes; produced = k + 1; }
                     cv.notify_all();
                     ++k;
                 }
