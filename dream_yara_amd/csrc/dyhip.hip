@@ -132,6 +132,8 @@ struct Tuning
     u64 dpSmallBlocks = 4096;   // grid of the thread-level aggregation kernels (k_finalize_small, k_pe_*): list-driven, grid-stride
     u64 dpAlignBlocks = 8192;   // grid of k_align_single
     u64 itemsSorted = 1;        // work list: 1 = (bin, read) pairs in read order + stable radix sort by bin, 0 = bin-major count matrix + scan + scatter
+    u64 asyncMap = 0;           // 1 = single-end batches after a context's first are queued whole (work list and pool sized from bounds, the real sizes read on the device, ONE fetch at the end);
+                                // 0 = the host waits for the work list's size and the pool counter.  Measured (config 2): 5.24 ms per step queued whole, 5.12 ms waiting — see DESIGN.md section 8
     u64 sweepChunk = 16384;     // reads per chunk of a deferred sweep (dy_ibf_query_deferred): ~60 us of K1, about one host round trip
 };
 
@@ -159,6 +161,8 @@ struct dy_ctx
            cursor, gp, aux, marr, maux, dp, scanTmp,
            shLen, shLenOff, shOwner, shTotals, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
     size_t poolCap = 0;
+    DevBuf devItems;                    // u32[4]: [0] the work list's size as the kernels see it, [1] as counted, [2] it did not fit (k_items_clamp)
+    double itemsPerRead = 0.0;          // of the last batch mapped: sizes the next batch's work list when nothing waits for its count
     PinnedBuf hostUp;                   // staging of dy_reads_upload
     PinnedBuf hostCounters, hostItems;
     PinnedBuf hostSlots[8];             // dy_host_buffer: pinned host memory the caller reads files into / writes files from (FASTQ in, SAM out)
@@ -370,7 +374,7 @@ template <int NW>
 static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink, u32 maxSeedLen)
 {
     hipLaunchKernelGGL(k_extend<NW>, dim3(((nItems + 255) / 256 + 7) / 8 * 8), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
-                       nItems, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>());
+                       ctx->devItemCount, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>());
     // re-seeded items: list-driven, spread thinly over a full grid (normally a tiny fraction of the items)
     // -y full: the edit-distance trie walk keeps one frame per level in a slab, one slice per wavefront of this grid
     const u32 hardBlocks = 2048;
@@ -405,15 +409,46 @@ static void collectSweepTime(dy_ctx * ctx, dy_reads * reads)
 
 static void fetchSync(dy_ctx * ctx);
 static void collectDeferredSweepTime(dy_ctx * ctx);
+template <typename TIn, typename TOut> static void exclusiveSum(dy_ctx * ctx, const TIn * in, TOut * out, size_t n);
 
 // Work list (bin-major): (read,bin) items of the masks on `reads` -> ctx->itemRead / itemBin / binStart (+ the local sortedBins() rank).
-static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
+// asyncCap = 0: the host waits for the list's size and sizes everything exactly (returns the size).  asyncCap > 0 (sorted list only): nothing
+// waits — the arrays hold asyncCap entries, the kernels take the size from ctx->devItems[0] (k_items_clamp; [1] = what was counted, devFlags[0] = it did
+// not fit) and the caller checks the flag when the whole step has run (returns asyncCap: the bound every later launch is sized by).
+static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins, u32 asyncCap = 0)
 {
         hipStream_t st = ctx->stream;
         const u32 nReads = reads->n, W = (nBins + 63) / 64;
         waitForMasks(ctx, reads);
         ctx->binStart.reserve((size_t)(nBins + 1) * 4); ctx->binOrderRank.reserve((size_t)nBins * 4);
+        ctx->devItems.reserve(64);
         u32 nItems = 0;
+        if (ctx->tune.itemsSorted && asyncCap)
+        {
+            const u64 nWords = (u64)nReads * W;
+            const u32 cap = asyncCap;
+            ctx->waveCounts.reserve((size_t)(nReads + 1) * 4); ctx->waveOffsets.reserve((size_t)(nReads + 1) * 4);
+            HIP_CHECK(hipMemsetAsync(ctx->waveCounts.p, 0, (size_t)(nReads + 1) * 4, st));
+            if (nWords) hipLaunchKernelGGL(k_items_word_count, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, nBins, ctx->waveCounts.as<u32>());
+            exclusiveSum(ctx, ctx->waveCounts.as<u32>(), ctx->waveOffsets.as<u32>(), (size_t)nReads + 1);
+            HIP_CHECK(hipMemsetAsync(ctx->devItems.p, 0, 16, st));
+            hipLaunchKernelGGL(k_items_clamp, dim3(1), dim3(1), 0, st, ctx->waveOffsets.as<u32>() + nReads, cap, ctx->devItems.as<u32>(), ctx->devItems.as<u32>() + 2);
+            ctx->devItemCount = ctx->devItems.as<u32>();
+            ctx->itemRead.reserve((size_t)cap * 4 + 64); ctx->itemBin.reserve((size_t)cap * 2 + 64);
+            ctx->itemKeys.reserve((size_t)cap * 4 + 64); ctx->itemPerm.reserve((size_t)cap * 4 + 64);
+            // slots behind the list sort to its end: key = nBins
+            HIP_CHECK(hipMemsetD16Async((hipDeviceptr_t)ctx->itemKeys.p, (unsigned short)nBins, cap, st));
+            if (nWords) hipLaunchKernelGGL(k_items_emit, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, nBins, ctx->waveOffsets.as<u32>(),
+                                           ctx->itemKeys.as<u16>(), ctx->itemPerm.as<u32>(), cap);
+            int bits = 1; while ((1u << bits) < nBins + 1) ++bits;
+            size_t sortBytes = 0;
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, ctx->itemKeys.as<u16>(), ctx->itemBin.as<u16>(), ctx->itemPerm.as<u32>(), ctx->itemRead.as<u32>(), (int)cap, 0, bits, st));
+            ctx->scanTmp.reserve(sortBytes + 64);
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ctx->scanTmp.p, sortBytes, ctx->itemKeys.as<u16>(), ctx->itemBin.as<u16>(), ctx->itemPerm.as<u32>(), ctx->itemRead.as<u32>(), (int)cap, 0, bits, st));
+            hipLaunchKernelGGL(k_items_bin_bounds, dim3((nBins + 1 + 255) / 256), dim3(256), 0, st, ctx->itemBin.as<u16>(), ctx->devItems.as<u32>(), nBins, ctx->binStart.as<u32>());
+            hipLaunchKernelGGL(k_items_bin_rank, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->binStart.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
+            return cap;
+        }
         if (ctx->tune.itemsSorted)
         {   // (bin, read) pairs in read order, stable radix sort by bin (map_kernels.h)
             const u64 nWords = (u64)nReads * W;
@@ -448,7 +483,7 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
             if (nItems)
             {
                 hipLaunchKernelGGL(k_items_emit, dim3((u32)((nWords + 255) / 256)), dim3(256), 0, st, reads->masks.as<u64>(), nWords, W, nBins, ctx->waveOffsets.as<u32>(),
-                                   ctx->itemKeys.as<u16>(), ctx->itemPerm.as<u32>());
+                                   ctx->itemKeys.as<u16>(), ctx->itemPerm.as<u32>(), nItems);
                 int bits = 1; while ((1u << bits) < nBins) ++bits;
                 size_t sortBytes = 0;
                 HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, ctx->itemKeys.as<u16>(), ctx->itemBin.as<u16>(), ctx->itemPerm.as<u32>(), ctx->itemRead.as<u32>(),
@@ -457,7 +492,10 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
                 HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(ctx->scanTmp.p, sortBytes, ctx->itemKeys.as<u16>(), ctx->itemBin.as<u16>(), ctx->itemPerm.as<u32>(), ctx->itemRead.as<u32>(),
                                                              (int)nItems, 0, bits, st));
             }
-            hipLaunchKernelGGL(k_items_bin_bounds, dim3((nBins + 1 + 255) / 256), dim3(256), 0, st, ctx->itemBin.as<u16>(), nItems, nBins, ctx->binStart.as<u32>());
+            HIP_CHECK(hipMemsetAsync(ctx->devItems.p, 0, 16, st));
+            hipLaunchKernelGGL(k_items_clamp, dim3(1), dim3(1), 0, st, ctx->waveOffsets.as<u32>() + nReads, nItems, ctx->devItems.as<u32>(), ctx->devItems.as<u32>() + 2);
+            ctx->devItemCount = ctx->devItems.as<u32>();
+            hipLaunchKernelGGL(k_items_bin_bounds, dim3((nBins + 1 + 255) / 256), dim3(256), 0, st, ctx->itemBin.as<u16>(), ctx->devItems.as<u32>(), nBins, ctx->binStart.as<u32>());
             hipLaunchKernelGGL(k_items_bin_rank, dim3((nBins + 255) / 256), dim3(256), 0, st, ctx->binStart.as<u32>(), nBins, ctx->binOrderRank.as<u32>());
             return nItems;
         }
@@ -489,13 +527,19 @@ static u32 buildWorkList(dy_ctx * ctx, dy_reads * reads, u32 nBins)
 }
 
 // Work list + K2 + K3: (read,bin) items of the masks on `reads` -> raw matches in ctx->pool, per-read counts in ctx->readMatchCount.
-static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, u32 S0, u32 & nItemsOut, u32 & nPoolOut)
+// async: nothing waits — the work list is sized from the previous batch's items per read, the pool keeps its capacity, nItemsOut / nPoolOut are
+// those BOUNDS (every later launch and allocation is sized by them, the kernels read the real sizes on the device) and the caller checks
+// devItems[2] / the pool's overflow flag once the whole step has run, mapping the batch again the waiting way if either is raised.
+static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, u32 S0, u32 & nItemsOut, u32 & nPoolOut, bool async = false)
 {
         hipStream_t st = ctx->stream;
         const u32 nReads = reads->n, nBins = (u32)idx->bins.size();
         HIP_CHECK(hipEventRecord(ctx->ev[2], st));
-        const u32 nItems = buildWorkList(ctx, reads, nBins);
-        ctx->stats.items = nItems;
+        u32 asyncCap = 0;
+        if (async) asyncCap = (u32)std::min<double>(2.0e9, (double)nReads * ctx->itemsPerRead * 1.25 + 4096.0);
+        const u32 nItems = buildWorkList(ctx, reads, nBins, asyncCap);
+        const u32 * nItemsDev = ctx->devItemCount;
+        ctx->stats.items = async ? 0 : nItems;
         HIP_CHECK(hipEventRecord(ctx->ev[3], st));
 
         // ---- K2: exact search of the round-0 seeds
@@ -507,7 +551,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         {
             u64 threads = (u64)nItems * 2 * S0;
             hipLaunchKernelGGL(k_seed_search, dim3((u32)(((threads + 255) / 256 + 7) / 8 * 8)), dim3(256), 0, st, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
-                               nItems, S0, mp.errorRate, ctx->hits0.as<uint2>());
+                               nItemsDev, S0, mp.errorRate, ctx->hits0.as<uint2>());
         }
         // ---- K3 work order: (bin, seeds found)
         ctx->itemKeys.reserve((size_t)nItems * 4 + 64); ctx->itemPerm.reserve((size_t)nItems * 4 + 64);
@@ -517,13 +561,13 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             if (nItems)
             {
                 HIP_CHECK(hipMemsetAsync(ctx->orderHist.p, 0, nKeys * 4, st));
-                hipLaunchKernelGGL(k_item_order_count, dim3((nItems + 1023) / 1024), dim3(1024), 0, st, ctx->hits0.as<uint2>(), ctx->itemBin.as<u16>(), nItems, S0,
+                hipLaunchKernelGGL(k_item_order_count, dim3((nItems + 1023) / 1024), dim3(1024), 0, st, ctx->hits0.as<uint2>(), ctx->itemBin.as<u16>(), nItemsDev, S0,
                                    ctx->itemKeys.as<u32>(), ctx->orderHist.as<u32>());
                 size_t tb = 0;
                 HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, ctx->orderHist.as<u32>(), ctx->orderCursor.as<u32>(), (int)nKeys, st));
                 ctx->scanTmp.reserve(tb + 64);
                 HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(ctx->scanTmp.p, tb, ctx->orderHist.as<u32>(), ctx->orderCursor.as<u32>(), (int)nKeys, st));
-                hipLaunchKernelGGL(k_item_order_scatter, dim3((nItems + 1023) / 1024), dim3(1024), 0, st, ctx->itemKeys.as<u32>(), nItems, ctx->orderCursor.as<u32>(),
+                hipLaunchKernelGGL(k_item_order_scatter, dim3((nItems + 1023) / 1024), dim3(1024), 0, st, ctx->itemKeys.as<u32>(), nItemsDev, ctx->orderCursor.as<u32>(),
                                    ctx->itemPerm.as<u32>());
             }
         }
@@ -557,6 +601,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
                 else launchExtend<128>(ctx, ix, rv, nItems, S0, mp, sink, maxSeedLen);
                 HIP_CHECK(hipGetLastError());
             }
+            if (async) break;                    // the counters are looked at when the step has run
             ctx->hostCounters.reserve(COUNTER_BYTES);
             HIP_CHECK(hipMemcpyAsync(ctx->hostCounters.p, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
             fetchSync(ctx);
@@ -570,9 +615,12 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             ctx->stats.pool_retries++;
         }
         HIP_CHECK(hipEventRecord(ctx->ev[5], st));
-        const u32 nPool = (u32)poolTotal;
-        ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12];     // re-seeded items, as the reference counts them
-
+        const u32 nPool = async ? (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u) : (u32)poolTotal;
+        if (!async)
+        {
+            ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12];     // re-seeded items, as the reference counts them
+            if (nReads) ctx->itemsPerRead = std::max(0.25, (double)nItems / (double)nReads);
+        }
         nItemsOut = nItems; nPoolOut = nPool;
 }
 
@@ -583,7 +631,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
 // ctx->peItems / peHasRescue from the owners' records and the work list of the home reads is in place.
 enum { PE_OWNER = 1, PE_HOME = 2 };
 static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, const dy_params * p, dy_result * res, const RawMatch * pool, u32 nPool,
-                        u32 nItems, u32 maxMatchErr, u32 peStages = PE_OWNER | PE_HOME)
+                        u32 nItems, u32 maxMatchErr, u32 peStages = PE_OWNER | PE_HOME, const u32 * nPoolDev = nullptr /* the real count, where nPool is only its bound */)
 {
         hipStream_t st = ctx->stream;
         const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
@@ -600,7 +648,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
         HIP_CHECK(hipMemsetAsync(ctx->cursor.p, 0, (size_t)nReads * 4, st));
         ctx->gp.reserve((size_t)nPool * sizeof(RawMatch) + 64);
         if (nPool)
-            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, pool, nPool, nReads, ctx->readStart.as<u32>(),
+            hipLaunchKernelGGL(k_group_matches, dim3((nPool + 255) / 256), dim3(256), 0, st, pool, nPool, nPoolDev, nReads, ctx->readStart.as<u32>(),
                                ctx->cursor.as<u32>(), ctx->gp.as<RawMatch>(), ctx->counters.as<u32>() + COUNTER_BAD_GROUP);
         ctx->aux.reserve((size_t)nPool * 16 + 64);
         const bool home = !paired || (peStages & PE_HOME), owner = !paired || (peStages & PE_OWNER);
@@ -873,7 +921,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
             {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255}, {"ibf_own_stream", &t.ibfOwnStream, 0, 1},
-            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1}, {"sweep_chunk", &t.sweepChunk, 1024, 2097151},
+            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1}, {"sweep_chunk", &t.sweepChunk, 1024, 2097151}, {"async_map", &t.asyncMap, 0, 1},
         };
         for (auto & k : keys)
             if (!strcmp(k.name, key))
@@ -1629,17 +1677,46 @@ int dy_map_reads_async(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, con
         ctx->stats.items = ctx->stats.raw_matches = ctx->stats.hard_items = ctx->stats.pool_retries = 0;
         if (nReads == 0) { *out = res.release(); return; }
 
-        u32 nItems = 0, nPool = 0;
-        runSearchExtend(ctx, idx, reads, p, S0, nItems, nPool);
-        res->nPool = nPool;
-        runFinalize(ctx, idx, reads, p, res.get(), ctx->pool.as<RawMatch>(), nPool, nItems, maxMatchErr);
-        HIP_CHECK(hipEventRecord(ctx->ev[6], st));
-
+        // Tuning key async_map: single-end batches are queued from the work list to the last aggregation kernel without the host waiting for a
+        // size (the waiting way has two round trips — work-list size, pool counter — that leave the device idle for 85 us per step): sizes are
+        // bounded from the previous batch, the kernels read the real ones on the device, and the ONE fetch at the end brings the flags that say
+        // whether the bounds held.  If not (or on a context's first batch, or for paired batches) the batch is mapped the waiting way.
+        // OFF by default: the idle time goes (0.195 -> 0.160 ms) but every small kernel of the chain then takes 2-3x as long when it is
+        // dispatched behind its predecessor instead of into an idle queue, and the padded sort / larger grids cost the rest: 5.24 vs 5.12 ms.
+        const bool canAsync = !paired && ctx->tune.itemsSorted && ctx->tune.asyncMap && ctx->itemsPerRead > 0.0 && ctx->poolCap > 0;
         res->readLens = reads->lens;       // for the host-side MAPQ (shared, not copied)
-        ctx->hostStatus.reserve(64);
-        HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.p, ctx->counters.as<u32>() + COUNTER_BAD_GROUP, 4, hipMemcpyDeviceToHost, st));
-        fetchSync(ctx);
-        if (*ctx->hostStatus.as<u32>()) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
+        for (int attempt = 0;; ++attempt)
+        {
+            const bool async = canAsync && attempt == 0;
+            u32 nItems = 0, nPool = 0;
+            runSearchExtend(ctx, idx, reads, p, S0, nItems, nPool, async);
+            res->nPool = nPool;
+            runFinalize(ctx, idx, reads, p, res.get(), ctx->pool.as<RawMatch>(), nPool, nItems, maxMatchErr, PE_OWNER | PE_HOME, async ? ctx->counters.as<u32>() + COUNTER_POOL64 : nullptr);
+            HIP_CHECK(hipEventRecord(ctx->ev[6], st));
+            ctx->hostStatus.reserve(COUNTER_BYTES + 64);
+            HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.p, ctx->counters.p, COUNTER_BYTES, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.as<u8>() + COUNTER_BYTES, ctx->devItems.p, 16, hipMemcpyDeviceToHost, st));
+            fetchSync(ctx);
+            const u32 * c = ctx->hostStatus.as<u32>(), * items = c + COUNTER_BYTES / 4;
+            if (async)
+            {
+                u64 poolTotal; memcpy(&poolTotal, c + COUNTER_POOL64, 8);
+                if (c[1] || items[2])
+                {   // a bound did not hold: once more, waiting for the sizes (the pool keeps what this pass learnt)
+                    if (c[1])
+                    {
+                        if (poolTotal >= 0xFFFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "more than 2^32 raw matches in one batch: use a smaller reads batch");
+                        ctx->poolCap = (size_t)poolTotal + (size_t)poolTotal / 4 + 1024;
+                    }
+                    ctx->stats.pool_retries++;
+                    continue;
+                }
+                ctx->stats.items = items[0]; ctx->stats.raw_matches = poolTotal; ctx->stats.hard_items = c[2] - c[12];
+                ctx->itemsPerRead = std::max(0.25, (double)items[0] / (double)nReads);
+            }
+            if (c[COUNTER_BAD_GROUP]) throw DyError(DY_EHIP, "internal error: a raw match record is inconsistent with the per-read counts");
+            break;
+        }
         collectDeferredSweepTime(ctx);
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_items = ms;

@@ -1477,10 +1477,12 @@ __global__ __launch_bounds__(256) void k_align_group(FinalizeArgs A, const u32 *
 // appended under: a read id outside the batch or more records of a read than were counted would index readStart / cursor / gp with
 // an arbitrary value (a GPU memory fault aborts the whole process), so such a record raises `bad` and is dropped instead — the host
 // turns the flag into DY_EHIP.  It cannot happen with the kernels in this library; the check costs one load per match.
-__global__ void k_group_matches(const RawMatch * __restrict__ pool, u32 nPool, u32 nReads, const u32 * __restrict__ readStart, u32 * __restrict__ cursor,
+// nPoolDev (may be NULL): the number of records, where only the device knows it yet (the host then passes the pool's capacity as nPool)
+__global__ void k_group_matches(const RawMatch * __restrict__ pool, u32 nPool, const u32 * __restrict__ nPoolDev, u32 nReads, const u32 * __restrict__ readStart, u32 * __restrict__ cursor,
                                 RawMatch * __restrict__ gp, u32 * __restrict__ bad)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nPoolDev) { const u32 n = *nPoolDev; if (n < nPool) nPool = n; }
     if (i >= nPool) return;
     const RawMatch m = pool[i];
     if (m.read >= nReads) { atomicExch(bad, 1u); return; }

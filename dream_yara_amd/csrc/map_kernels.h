@@ -263,8 +263,9 @@ __global__ void k_items_word_count(const u64 * __restrict__ masks, u64 nWords, u
     if (m) atomicAdd(&readCount[t / W], (u32)__popcll(m));
 }
 
+// cap: entries the arrays hold (the list's size is not known on the host when the kernels are queued, see k_items_clamp)
 __global__ void k_items_emit(const u64 * __restrict__ masks, u64 nWords, u32 W, u32 nBins, const u32 * __restrict__ readOffset,
-                             u16 * __restrict__ keys, u32 * __restrict__ vals)
+                             u16 * __restrict__ keys, u32 * __restrict__ vals, u32 cap)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nWords) return;
@@ -279,16 +280,26 @@ __global__ void k_items_emit(const u64 * __restrict__ masks, u64 nWords, u32 W, 
         m &= m - 1;
         const u32 bin = w * 64 + j;
         if (bin >= nBins) break;
-        keys[dst] = (u16)bin; vals[dst] = read; ++dst;
+        if (dst < cap) { keys[dst] = (u16)bin; vals[dst] = read; }
+        ++dst;
     }
 }
 
+// The work list's size as every later kernel sees it: what was counted, or the capacity of the arrays if that is smaller — then flags[0]
+// is raised and the host, which queued the whole step without waiting for the count, maps the batch again with room enough.
+__global__ void k_items_clamp(const u32 * __restrict__ counted, u32 cap, u32 * __restrict__ nItems, u32 * __restrict__ flags)
+{
+    const u32 n = *counted;
+    nItems[0] = n < cap ? n : cap; nItems[1] = n;
+    if (n > cap) flags[0] = 1;
+}
+
 // binStart[b] = first item of bin b in the sorted keys (nItems for b = nBins)
-__global__ void k_items_bin_bounds(const u16 * __restrict__ keys, u32 nItems, u32 nBins, u32 * __restrict__ binStart)
+__global__ void k_items_bin_bounds(const u16 * __restrict__ keys, const u32 * __restrict__ nItemsDev, u32 nBins, u32 * __restrict__ binStart)
 {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nBins) return;
-    u32 lo = 0, hi = nItems;
+    u32 lo = 0, hi = *nItemsDev;
     while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (keys[mid] < b) lo = mid + 1; else hi = mid; }
     binStart[b] = lo;
 }
@@ -334,11 +345,15 @@ __global__ void k_items_scatter(const u64 * __restrict__ masks, u32 nReads, u32 
 // (seeds are stored in descending offset order, reference src/mapper_collector.h:166-171).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead,
-                                                     const u16 * __restrict__ itemBin, u32 nItems, u32 S0, float errorRate,
+                                                     const u16 * __restrict__ itemBin, const u32 * __restrict__ nItemsDev, u32 S0, float errorRate,
                                                      uint2 * __restrict__ hits0)
 {
-    const u64 t = (u64)xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    // the grid is sized for the arrays' capacity; the blocks the list needs are remapped among themselves
+    const u32 nItems = *nItemsDev;
     const u32 slots = 2 * S0;
+    const u32 useful = (u32)((((u64)nItems * slots + 255) / 256 + 7) / 8 * 8);
+    if (blockIdx.x >= useful) return;
+    const u64 t = (u64)xcdRemapBlock(blockIdx.x, useful) * blockDim.x + threadIdx.x;
     const u32 item = (u32)(t / slots), slot = (u32)(t % slots);
     if (item >= nItems) return;
     const u32 strand = slot / S0, seedId = slot % S0;
@@ -693,18 +708,22 @@ __device__ __forceinline__ u32 blockKeySlot(bool valid, u32 key, u32 * __restric
     else if (valid) slot = atomicAdd(&counters[key], 1u);
     return slot;
 }
-__global__ __launch_bounds__(1024) void k_item_order_count(const uint2 * __restrict__ hits0, const u16 * __restrict__ itemBin, u32 nItems, u32 S0,
+__global__ __launch_bounds__(1024) void k_item_order_count(const uint2 * __restrict__ hits0, const u16 * __restrict__ itemBin, const u32 * __restrict__ nItemsDev, u32 S0,
                                                            u32 * __restrict__ keys, u32 * __restrict__ hist)
 {
+    const u32 nItems = *nItemsDev;
+    if (blockIdx.x * blockDim.x >= nItems) return;            // (uniform per block: no thread of it reaches the barriers below)
     const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = item < nItems;
     u32 key = 0;
     if (valid) { key = itemOrderKey(hits0 + (size_t)item * 2 * S0, S0, itemBin[item]); keys[item] = key; }
     (void)blockKeySlot(valid, key, hist);
 }
-__global__ __launch_bounds__(1024) void k_item_order_scatter(const u32 * __restrict__ keys, u32 nItems, u32 * __restrict__ cursor /* = exclusive scan of hist */,
+__global__ __launch_bounds__(1024) void k_item_order_scatter(const u32 * __restrict__ keys, const u32 * __restrict__ nItemsDev, u32 * __restrict__ cursor /* = exclusive scan of hist */,
                                                              u32 * __restrict__ perm)
 {
+    const u32 nItems = *nItemsDev;
+    if (blockIdx.x * blockDim.x >= nItems) return;
     const u32 item = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = item < nItems;
     const u32 key = valid ? keys[item] : 0;
@@ -939,10 +958,13 @@ __device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read
 
 template <int NW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? DY_K3_WAVES : 1, NW <= 2 ? DY_K3_WAVES : 8))) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
-                                                u32 nItems, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
+                                                const u32 * __restrict__ nItemsDev, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
                                                 u32 * __restrict__ hardCount, u32 * __restrict__ hardList, const u32 * __restrict__ perm)
 {
-    const u32 idx = xcdRemapBlock(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
+    const u32 nItems = *nItemsDev;
+    const u32 useful = ((nItems + 255) / 256 + 7) / 8 * 8;
+    if (blockIdx.x >= useful) return;                         // uniform per block
+    const u32 idx = xcdRemapBlock(blockIdx.x, useful) * blockDim.x + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
     ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
     u32 read = 0;

@@ -57,7 +57,9 @@ void       *dy_ctx_stream(dy_ctx *ctx);
  * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next
  * batch's sweep can be queued before the current batch is mapped), dp_small_blocks (64-65536, 4096) and dp_align_blocks (64-65536, 8192: grids of the
  * thread-level aggregation / alignment kernels), items_sorted (0-1, 1: work list as (bin, read) pairs + stable radix sort; 0 = bin-major
- * count matrix), sweep_chunk (1024-2097151, 16384: reads per chunk of a deferred sweep), pool_cap (initial raw-match
+ * count matrix), sweep_chunk (1024-2097151, 16384: reads per chunk of a deferred sweep), async_map (0-1, 0: 1 = single-end batches after a context's
+ * first are queued whole — work list and pool sized from bounds, real sizes read on the device, one fetch at the end; measured slower than waiting for
+ * the two sizes), pool_cap (initial raw-match
  * pool capacity, 0 = automatic; the pool grows and the extension is re-run on overflow).  Stands where the reference has
  * compile-time template switches (reference src/mapper.h:128-206 MapperConfig / Limits).  Unknown key or value: DY_EINVAL. */
 int         dy_ctx_set_tuning(dy_ctx *ctx, const char *key, uint64_t value);

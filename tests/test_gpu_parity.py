@@ -406,6 +406,41 @@ def test_device_fastq_parse_and_sam_format_equal_the_host_path(product_build, dy
         c.close()
 
 
+def test_batches_queued_whole_equal_the_waiting_way(dy, ob, small_filter):
+    """Tuning key async_map: after a context's first batch, single-end batches are queued without the host waiting for the work list's size or
+    the pool counter (bounds from the previous batch, real sizes on the device, flags fetched at the end).  Same results as the oracle — also
+    when a bound does not hold (a batch four times the previous one: the work list does not fit, the batch is mapped again the waiting way)."""
+    c = dy.Context(0)
+    try:
+        c.set_tuning("async_map", 1)
+        _, codes, offs = read_fasta_codes(READS_FA)
+        er = np.float32(3 / 100.0)
+        idx = dy.Index(c, GOLD_INDEX, 64)
+        ibf = dy.Ibf.load(c, small_filter)
+        thr = dy.threshold(er, 19, 100)
+        params = dy.default_params(error_rate=er, strata_rate=np.float32(0.10))
+        oidx = ob.OracleIndex(GOLD_INDEX, 64); oibf = ob.OracleIbf(small_filter)
+        retries = []
+        # first: waiting; second: queued whole; third: unfiltered (64 items per read instead of one: the work list does not fit); fourth: queued whole
+        for lo, hi, filtered in ((0, 1500, True), (1500, 3000, True), (3000, 4000, False), (4000, 6400, True)):
+            cc, oo = codes[int(offs[lo]): int(offs[hi])], (offs[lo: hi + 1] - offs[lo]).astype(np.uint64)
+            reads = dy.Reads(c, cc, oo)
+            params.use_filter = 1 if filtered else 0
+            if filtered:
+                ibf.query(reads, thr, want_masks=False)
+            res = dy.map_reads(c, idx, reads, params)
+            got = (res.reads(), res.matches(), res.cigars()); st = c.stats()
+            res.close(); reads.close()
+            o = ob.map_batch(oidx, oibf if filtered else None, cc, oo, er, np.float32(0.10))
+            assert_results_equal(got, o[:3])
+            assert st["items"] == o[3]["items"] and st["raw_matches"] == o[3]["raw_matches"]
+            retries.append(st["pool_retries"])
+        assert retries[1:] == [0, 1, 0]                       # (the first batch may grow the pool the waiting way)
+        oidx.close(); oibf.close(); ibf.close(); idx.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("chunk", [1024, 16384])
 def test_deferred_sweep_gives_the_same_masks_and_results(dy, ob, small_filter, chunk):
     """dy_ibf_query_deferred: the sweep of the batch mapped next is queued chunk by chunk in front of the host's waits of the current
@@ -453,7 +488,7 @@ def test_deferred_sweep_gives_the_same_masks_and_results(dy, ob, small_filter, c
 
 
 @pytest.mark.parametrize("tuning", [{"sparse_sa": 1}, {"prefix_q": 0}, {"no_isa": 1}, {"prefix_q": 6}, {"finalize_block_min": 3, "finalize_no_keys": 1},
-                                    {"ibf_full_tail": 1}, {"items_sorted": 0}])
+                                    {"ibf_full_tail": 1}, {"items_sorted": 0}, {"async_map": 1}])
 def test_map_without_the_device_only_tables(dy, ob, small_filter, tuning):
     """The HBM-sized tables (expanded SA, q-mer ranges, inverse SA + indexed text) only accelerate: with each of them switched
     off at load time (dy_ctx_set_tuning) the results stay identical to the oracle (sparse-SA walk, plain LF search, row-range
