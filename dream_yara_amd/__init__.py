@@ -166,6 +166,12 @@ class Context:
     def sync(self):
         _check(self.lib.dy_ctx_sync(self.h))
 
+    def host_buffer(self, slot, nbytes):
+        """Address of the context's pinned host slot (device-accessible), at least nbytes large."""
+        out = _P()
+        _check(self.lib.dy_host_buffer(self.h, slot, nbytes, C.byref(out)))
+        return out.value
+
     def background_chunk(self, max_reads=0):
         """One chunk of the pending deferred sweep, to be called right before waiting for an event recorded on the context's stream."""
         _check(self.lib.dy_ctx_background_chunk(self.h, max_reads))

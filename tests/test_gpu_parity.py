@@ -406,6 +406,68 @@ def test_device_fastq_parse_and_sam_format_equal_the_host_path(product_build, dy
         c.close()
 
 
+def test_owner_side_batch_ignores_mask_bits_beyond_the_bins(dy, ob, small_filter, tmp_path):
+    """A C1 segment as a peer rank would send it, built by hand, with stray bits above the last bin in every read's mask word (6 bins: bits 6..63)
+    and the bit of a bin this rank does not own: the owner-side work list counts and emits the same (read, bin) pairs (the count pass masks the
+    last word like the emit pass does, and dy_map_bins ANDs the masks with the resident bins), so loads, raw matches and final results equal
+    those of clean masks.  One rank, no transport: the packed send buffer is handed back as the receive buffer."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n_bins, k = 6, 16
+    genomes, fam = _repeat_genomes(rng, n_bins, 30000)
+    idx_dir = str(tmp_path / "idx"); os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
+    fpath = str(tmp_path / "f.filter")
+    ob.build_filter(fpath, n_bins, 3, k, 1 << 24, np.concatenate(genomes), goffs)
+    codes, offs = _sample_reads(rng, genomes, fam, 500, 100, 3)
+    n = offs.size - 1
+    c = dy.Context(0)
+    try:
+        ibf = dy.Ibf.load(c, fpath)
+        owned = np.array([1, 1, 1, 1, 1, 0], np.uint8)                           # bin 5 lives on another rank
+        idx = dy.Index(c, idx_dir, n_bins, owned=owned)
+        reads = dy.Reads(c, codes, offs)
+        er = np.float32(0.03)
+        masks = ibf.query(reads, dy.threshold(er, k, 100))[:, 0]
+        params = dy.default_params(error_rate=er)
+        row_bytes = dy.shard_c2_row_bytes(n_bins)
+
+        def run(m):
+            lens = np.diff(offs).astype(np.uint32)
+            body = np.arange(n, dtype=np.uint32).tobytes() + lens.tobytes()
+            body += b"\0" * (-len(body) % 16) + m.astype("<u8").tobytes() + codes.tobytes()
+            body += b"\0" * (-len(body) % 16)
+            hdr = np.zeros(1, dy.SEG_HEADER_DTYPE)
+            hdr["n_reads"], hdr["n_bases"], hdr["bytes"], hdr["aux"] = n, codes.size, len(body), 100 | (100 << 32)
+            seg = c.host_buffer(0, len(body))                                    # pinned: the kernels read it where it lies
+            C.memmove(seg, body, len(body))
+            sub = dy.shard_c1_unpack(c, seg, hdr, n_bins, False)
+            loads, n_raw = dy.map_bins(c, idx, sub, params)
+            rows = c.host_buffer(1, row_bytes)
+            send = dy.shard_c2_pack(c, rows)
+            c.sync(); sub.close()
+            rows_host = np.frombuffer(C.string_at(rows, row_bytes), dtype=np.uint8).copy()
+            assert int(rows_host[:8].view("<u8")[0]) == n_raw
+            res = dy.shard_finalize(c, idx, reads, params, send, rows_host, 1)
+            res.fetch()
+            out = (res.reads(), res.matches(), res.cigars())
+            res.close()
+            return loads, n_raw, out
+        clean = masks & np.uint64(0b011111)
+        dirty = masks | np.uint64(0xFFFFFFFFFFFFFFC0) | np.uint64(0b100000)
+        l0, r0, o0 = run(clean)
+        l1, r1, o1 = run(dirty)
+        assert l0[5] == 0 and np.array_equal(l0, l1) and int(l0.sum()) == int(np.unpackbits(clean.view(np.uint8)).sum())
+        assert r0 == r1 and r0 > 300
+        assert_results_equal(o0, o1)
+        assert int(o0[0]["mapped"].sum()) > 300
+        reads.close(); idx.close(); ibf.close()
+    finally:
+        c.close()
+
+
 def test_batches_queued_whole_equal_the_waiting_way(dy, ob, small_filter):
     """Tuning key async_map: after a context's first batch, single-end batches are queued without the host waiting for the work list's size or
     the pool counter (bounds from the previous batch, real sizes on the device, flags fetched at the end).  Same results as the oracle — also
