@@ -228,7 +228,8 @@ class Setup:
         if mode == "bins":
             from dream_yara_amd import sharded
             sm = sharded.ShardedMapper(ctx, grp.dist, rank, world, self.idx_dir, wl["bins"], self.ibf, "cuda",
-                                       prefetch=args.prefetch == "on" or (args.prefetch == "auto" and world > 1))
+                                       prefetch=args.prefetch == "on" or (args.prefetch == "auto" and world > 1),
+                                       overlap_transfers=None if args.overlap_transfers == "auto" else args.overlap_transfers == "on")
             index = sm.index
         else:
             index = dy.Index(ctx, self.idx_dir, wl["bins"])
@@ -517,6 +518,8 @@ def main():
     ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
                     help="bins-sharded leg: queue the next batch's IBF sweep in chunks in front of the host's waits (count fetches, peers).  auto = on with more than one rank "
                          "(on one GPU the waits are short: 5.96 ms per step without, 6.00 ms with)")
+    ap.add_argument("--overlap-transfers", default="auto", choices=["auto", "on", "off"],
+                    help="bins-sharded leg with --prefetch: a chunk of the next sweep sized to the transfer runs beside each all-to-all(v) (auto = with more than one rank)")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
                     help="N = 1: also measure the other geometries, the bins-sharded partitioning through RCCL, the PCIe-inclusive and the end-to-end rates (auto = with the default workload)")
     ap.add_argument("--extras-budget", type=float, default=420.0, help="seconds of wall clock after which no further extra measurement is started")

@@ -138,6 +138,18 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libdyhip.so is not built (%s); run: python -m dream_yara_amd.build" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64.so.7 (+ HSA runtime) and the harness uses torch.distributed next to this
+    # library.  Whichever copy is loaded first serves both (same SONAME) — but if ROCm's copy came first, torch's other libraries bring a second
+    # HSA runtime along and torch finds no GPU.  So torch's copy, when there is one, is loaded before libdyhip (no import of torch needed).
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.origin:
+            hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+    except (ImportError, OSError, ValueError):
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the ABI and the header drifted apart

@@ -107,15 +107,22 @@ def exchange_rows(dist, rows, row_bytes, world, stream=None, pinned=None, before
     return mine.numpy().reshape(world, row_bytes), got.numpy().reshape(world, row_bytes)
 
 
-def exchange_segments(dist, send, send_bytes, recv_bytes, device):
+def exchange_segments(dist, send, send_bytes, recv_bytes, device, during=None):
     """ONE all-to-all(v) of a packed uint8 buffer (segments destination-major).  Returns the received buffer on `device`; with nccl nothing
-    waits on the host (work queued on the current stream afterwards sees the data)."""
+    waits on the host (work queued on the current stream afterwards sees the data).
+    during (nccl): called once the transfer is queued on RCCL's stream and before the current stream is made to wait for it — what it queues on
+    the current stream (a chunk of the next batch's sweep) runs beside the transfer, which holds a few workgroups only and started first."""
     if dist is None:
         return send
     ss, rs = [int(x) for x in send_bytes], [int(x) for x in recv_bytes]
     if dist.get_backend() == "nccl":
         out = torch.empty(sum(rs), dtype=torch.uint8, device=device)
-        dist.all_to_all_single(out, send[: sum(ss)], output_split_sizes=rs, input_split_sizes=ss)
+        if during is None:
+            dist.all_to_all_single(out, send[: sum(ss)], output_split_sizes=rs, input_split_sizes=ss)
+        else:
+            work = dist.all_to_all_single(out, send[: sum(ss)], output_split_sizes=rs, input_split_sizes=ss, async_op=True)
+            during()
+            work.wait()                       # a stream-level wait: the host goes on
         return out
     src = send[: sum(ss)].cpu()
     out = torch.empty(sum(rs), dtype=torch.uint8)
@@ -160,7 +167,7 @@ class ShardedMapper:
     """One rank of a bin-sharded job: replicated filter + contigs, FM structures of the bins this rank owns.
     dist = None: a single rank without a process group (the packed send buffer is the receive buffer)."""
 
-    def __init__(self, ctx, dist, rank, world, index_dir, n_bins, ibf, device, assignment="lpt", prefetch=False):
+    def __init__(self, ctx, dist, rank, world, index_dir, n_bins, ibf, device, assignment="lpt", prefetch=False, overlap_transfers=None):
         self.ctx, self.dist, self.rank, self.world, self.ibf, self.device = ctx, dist, rank, world, ibf, device
         self.n_bins, self.W = n_bins, (n_bins + 63) // 64
         self.owner = bin_owner(n_bins, world, bin_sizes(index_dir, n_bins) if assignment == "lpt" else None)
@@ -169,6 +176,8 @@ class ShardedMapper:
         self.row2 = dy.shard_c2_row_bytes(n_bins)
         self.stream = torch.cuda.ExternalStream(ctx.stream()) if device != "cpu" else None
         self.prefetch = bool(prefetch)
+        # with a deferred sweep at hand, a chunk of it sized to the transfer runs beside each all-to-all(v) (default: when there are peers to wait for)
+        self.overlap_transfers = (world > 1) if overlap_transfers is None else bool(overlap_transfers)
         with self._on_stream():
             self.hdr = torch.zeros(world * dy.SEG_HEADER_BYTES, dtype=torch.uint8, device=device)
             self.rows = torch.zeros(world * self.row2, dtype=torch.uint8, device=device)
@@ -206,7 +215,7 @@ class ShardedMapper:
             h_out = np.ascontiguousarray(mine).view(dy.SEG_HEADER_DTYPE).reshape(world)
             h_in = np.ascontiguousarray(theirs).view(dy.SEG_HEADER_DTYPE).reshape(world)
             send = device_view(send_ptr, int(h_out["bytes"].sum()), dev)
-            recv = exchange_segments(self.dist, send, h_out["bytes"], h_in["bytes"], dev)
+            recv = exchange_segments(self.dist, send, h_out["bytes"], h_in["bytes"], dev, self._beside(chunk, h_out["bytes"]))
             sub = dy.shard_c1_unpack(ctx, recv.data_ptr() if recv.numel() else None, h_in, self.n_bins, paired)
             dy.map_bins(ctx, self.index, sub, params, want_counts=False)               # K2 + K3 (+ pairing, rescue) on the owner
             # ---- C2: raw matches (+ pairing records) -> the read's home rank
@@ -216,7 +225,7 @@ class ShardedMapper:
             r_out = np.ascontiguousarray(mine[:, : dy.SEG_HEADER_BYTES]).view(dy.SEG_HEADER_DTYPE).reshape(world)
             r_in = np.ascontiguousarray(theirs[:, : dy.SEG_HEADER_BYTES]).view(dy.SEG_HEADER_DTYPE).reshape(world)
             send2 = device_view(send_ptr, int(r_out["bytes"].sum()), dev)
-            recv2 = exchange_segments(self.dist, send2, r_out["bytes"], r_in["bytes"], dev)
+            recv2 = exchange_segments(self.dist, send2, r_out["bytes"], r_in["bytes"], dev, self._beside(chunk, r_out["bytes"]))
             res = dy.shard_finalize(ctx, self.index, reads, params, recv2.data_ptr() if recv2.numel() else None, theirs, world)    # K4 on the home rank
             loads = np.ascontiguousarray(theirs[:, dy.SEG_HEADER_BYTES: dy.SEG_HEADER_BYTES + 4 * self.n_bins]).view("<u4").reshape(world, self.n_bins)
             self.last = {"sent_reads": int(h_out["n_reads"].sum()), "recv_reads": int(h_in["n_reads"].sum()), "raw_out": int(r_out["n_reads"].sum()),
@@ -224,6 +233,15 @@ class ShardedMapper:
                          "c1_bytes_out": int(h_out["bytes"].sum()), "c2_bytes_out": int(r_out["bytes"].sum())}
             self._keep = [recv, recv2, send, send2]
         return res
+
+    def _beside(self, chunk, bytes_out):
+        """What runs beside an all-to-all(v): a chunk of the pending sweep about as long as the transfer (bytes to the peers over ~300 GB/s of xGMI
+        links; the sweep passes ~285 M reads/s: one read per 1 000 bytes on the links), at least the default chunk."""
+        if chunk is None or not self.overlap_transfers or self.dist is None or self.dist.get_backend() != "nccl":
+            return None
+        remote = int(bytes_out.sum()) - int(bytes_out[self.rank])
+        n = max(16384, remote // 1000)
+        return lambda: chunk(n)
 
     def close(self):
         # torch's caching allocator ties the blocks it handed out under the context's stream to that stream (and records events on it): they
