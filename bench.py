@@ -194,8 +194,11 @@ class Setup:
         t0 = time.time()
         self.per_batch = wl.get("batch", wl["reads"])
         self.n_batches = wl["reads"] // self.per_batch
+        # a step maps n_batches batches; with one batch per step a second resident batch (other reads of the same simulation) lets consecutive
+        # steps alternate, so that the sweep of the batch mapped next can be queued while the current one is mapped (dy_ibf_query_deferred)
+        self.n_resident = max(self.n_batches, 2) if args.pipeline != "off" and not paired else self.n_batches
         self.batches, self.truths, self.host_batch0 = [], [], None
-        for bi in range(self.n_batches):
+        for bi in range(self.n_resident):
             seed = shard_seed(4 if paired else 2, rank) + 7919 * bi
             if paired:
                 codes, offs, ptruth = synth.simulate_pairs(genomes, self.per_batch // 2, wl["L"], seed=seed)
@@ -208,7 +211,7 @@ class Setup:
                 self.host_batch0 = (codes, offs)
                 self.truths.append(truth_bin)
         del genomes
-        log("rank %d: %s: %d reads simulated + uploaded in %.1f s" % (rank, name, wl["reads"], time.time() - t0))
+        log("rank %d: %s: %d reads simulated + uploaded in %.1f s" % (rank, name, self.n_resident * self.per_batch, time.time() - t0))
         self.error_rate = np.float32(wl["e"] / 100.0)
         self.params = dy.default_params(error_rate=self.error_rate, paired=1 if paired else 0)
         self.thr = dy.threshold(self.error_rate, wl["k"], wl["L"])
@@ -237,16 +240,26 @@ class Setup:
         info = index.info()
         batches, params, thr = self.batches, self.params, self.thr
 
-        def step(keep_first, more_steps=False):
-            kept, st_sum, items, raws, st = None, {k: 0.0 for k in STAGES}, 0, 0, None
-            for bi, reads in enumerate(batches):
+        nb, per_step = len(batches), self.n_batches
+        pipeline = sm is None and nb > 1 and args.pipeline != "off"
+        state = {"at": 0, "swept": None, "kept": None}
+
+        def step(keep, more_steps=False):
+            """Maps the next per_step batches (round robin over the resident ones).  The sweep of the batch mapped NEXT is registered before the
+            current one is mapped (same work inside the timed region: the first step sweeps its own batch, the last one registers nothing)."""
+            st_sum, items, raws, st = {k: 0.0 for k in STAGES}, 0, 0, None
+            for j in range(per_step):
+                reads = batches[state["at"] % nb]
+                nxt = batches[(state["at"] + 1) % nb] if (j + 1 < per_step or more_steps) else None
                 if sm is not None:
-                    # the sweep of the batch mapped next may be queued, in chunks, in front of this batch's waits (same work inside the
-                    # timed region: the first step sweeps its own batch, the last one queues nothing)
-                    nxt = batches[bi + 1] if bi + 1 < len(batches) else (batches[0] if more_steps else None)
                     res = sm.map(reads, params, thr, next_reads=nxt)
                 else:
-                    self.ibf.query(reads, thr, want_masks=False)
+                    if state["swept"] is not reads:
+                        self.ibf.query(reads, thr, want_masks=False)
+                    state["swept"] = None
+                    if pipeline and nxt is not None and nxt is not reads:
+                        self.ibf.query_deferred(nxt, thr)
+                        state["swept"] = nxt
                     res = dy.map_reads(ctx, index, reads, params, asynchronous=True)
                 ctx.sync()
                 st = ctx.stats()
@@ -254,31 +267,34 @@ class Setup:
                     st_sum[k] += st[k]
                 items += (st["items"] if sm is None else sm.last["items"] / world)
                 raws += st["raw_matches"]
-                if keep_first and bi == 0:
-                    kept = res
+                if keep and state["at"] % nb == 0:                  # the result of the first resident batch: the one the parity sample belongs to
+                    if state["kept"] is not None:
+                        state["kept"].close()
+                    state["kept"] = res
                 else:
                     res.close()
-            return kept, st_sum, items, raws, st
+                state["at"] += 1
+            return st_sum, items, raws, st
 
-        for _ in range(warmup):
-            step(False)
+        for i in range(warmup):
+            step(False, more_steps=i + 1 < warmup)
         ctx.sync()
+        state["at"] = 0
         stage_ms = {k: 0.0 for k in STAGES}
         grp.barrier(); torch.cuda.synchronize(); ctx.sync()
         t_start = time.perf_counter()
-        last, items, raws, st = None, 0, 0, None
+        items, raws, st = 0, 0, None
         for i in range(steps):
-            kept, st_sum, items, raws, st = step(i + 1 == steps, more_steps=i + 1 < steps)
+            st_sum, items, raws, st = step(True, more_steps=i + 1 < steps)
             for k in STAGES:
                 stage_ms[k] += st_sum[k]
-            if kept is not None:
-                last = kept
         ctx.sync(); torch.cuda.synchronize(); grp.barrier()
+        last = state["kept"]
         elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
         from dream_yara_amd.dist import whole_job_rate
         steps = max(1, steps)
         out = {"value": whole_job_rate(wl["reads"], steps, world, elapsed), "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
-               "parallelism": ("reads sharded x%d, filter+index replicated, no data-path collective" % world) if sm is None else
+               "parallelism": ("reads sharded x%d, filter+index replicated, no data-path collective%s" % (world, "; %d resident batches mapped in turn, the next batch's sweep queued beside the current batch's last aggregation kernels" % nb if pipeline else "")) if sm is None else
                               ("bins sharded x%d (LPT on the bins' sizes: bin mod N for equal bins), filter+contigs replicated, reads->owners and raw matches->home "
                                "by two packed all-to-alls over RCCL%s" % (world, ", next sweep queued in chunks in front of the host's waits" if sm.prefetch else "")),
                "items_per_read": items / wl["reads"], "raw_matches_per_read": raws / wl["reads"],
@@ -382,7 +398,7 @@ class Setup:
         mapped = rr["mapped"] == 1
         truth = self.truths[0]
         cfg = {"workload": self.wl["desc"] + (" — PAIRED: %d pairs per step, insert N(400,40)" % (self.wl["reads"] // 2) if self.paired else ""),
-               "reads_per_gpu_per_step": self.wl["reads"], "resident_batches": self.n_batches, "parallelism": leg["parallelism"],
+               "reads_per_gpu_per_step": self.wl["reads"], "batches_per_step": self.n_batches, "resident_batches": self.n_resident, "parallelism": leg["parallelism"],
                "mapped_fraction": float(mapped.mean()), "primary_in_true_bin": float((rr["primary"]["contig"][mapped] == truth[mapped]).mean()),
                "items_per_read": leg["items_per_read"], "raw_matches_per_read": leg["raw_matches_per_read"],
                "stage_ms_per_step": leg["stage_ms_per_step"], "device_tables": leg["device_tables"]}
@@ -518,6 +534,9 @@ def main():
     ap.add_argument("--prefetch", default="auto", choices=["auto", "on", "off"],
                     help="bins-sharded leg: queue the next batch's IBF sweep in chunks in front of the host's waits (count fetches, peers).  auto = on with more than one rank "
                          "(on one GPU the waits are short: 5.96 ms per step without, 6.00 ms with)")
+    ap.add_argument("--pipeline", default="off", choices=["on", "off"],
+                    help="unsharded leg: keep (at least) two resident batches and register the next batch's IBF sweep before the current one is mapped (dy_ibf_query_deferred); "
+                         "measured neutral on one GPU (5.10 vs 5.09 ms per step): nothing runs beside a sweep")
     ap.add_argument("--overlap-transfers", default="auto", choices=["auto", "on", "off"],
                     help="bins-sharded leg with --prefetch: a chunk of the next sweep sized to the transfer runs beside each all-to-all(v) (auto = with more than one rank)")
     ap.add_argument("--extras", default="auto", choices=["auto", "on", "off"],
@@ -660,7 +679,7 @@ def main():
                 p = w.parity(res_w, 200000, min(effective_cpus(), 64), ob)
                 line["workloads"][name] = {
                     "workload": w.wl["desc"], "value": leg_w["value"], "unit": "reads/s", "ms_per_step": leg_w["ms_per_step"], "steps": steps_w, "warmup": 1,
-                    "resident_batches": w.n_batches, "stage_ms_per_step": leg_w["stage_ms_per_step"],
+                    "batches_per_step": w.n_batches, "resident_batches": w.n_resident, "stage_ms_per_step": leg_w["stage_ms_per_step"],
                     "k1": {"kernel": roof["kernel"], "launch_ms": roof["launch_ms"], "effective_algorithmic_frac": roof["frac"], "effective_algorithmic_GBps": roof["achieved"],
                            "line_slot_frac_of_hbm_peak": roof["line_slots"]["frac_of_hbm_peak"] if roof["line_slots"] else None,
                            "line_slot_source": roof["traffic_source"], "first_check_slack": leg_w["ibf_first_check_slack"], "tail_pre": leg_w["ibf_tail_pre"]},

@@ -134,7 +134,8 @@ struct Tuning
     u64 itemsSorted = 1;        // work list: 1 = (bin, read) pairs in read order + stable radix sort by bin, 0 = bin-major count matrix + scan + scatter
     u64 asyncMap = 0;           // 1 = single-end batches after a context's first are queued whole (work list and pool sized from bounds, the real sizes read on the device, ONE fetch at the end);
                                 // 0 = the host waits for the work list's size and the pool counter.  Measured (config 2): 5.24 ms per step queued whole, 5.12 ms waiting — see DESIGN.md section 8
-    u64 sweepChunk = 16384;     // reads per chunk of a deferred sweep (dy_ibf_query_deferred): ~60 us of K1, about one host round trip
+    u64 sweepChunk = 0;         // reads per chunk of a deferred sweep queued in front of each host wait (16384 = ~60 us of K1, about one round trip); 0 = no chunks:
+                                // the whole sweep runs when its masks are first needed
 };
 
 struct dy_ibf; struct dy_reads;
@@ -152,8 +153,8 @@ struct dy_ctx
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     hipStream_t ibfStream = nullptr;   // K1 runs here: the sweep of the NEXT batch overlaps K2..K4 of the current one (dy_map_reads waits for the batch's own sweep)
-    hipStream_t side[2] = {};          // K4's list kernels are latency-bound on a handful of waves each: they run side by side
-    hipEvent_t evFork = nullptr, evJoin[2] = {};
+    hipStream_t side[3] = {};          // K4's list kernels are latency-bound on a handful of waves each: they run side by side
+    hipEvent_t evFork = nullptr, evJoin[3] = {};
     dy_map_stats stats = {};
     // workspaces (grow-only, reused across batches)
     DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
@@ -703,17 +704,19 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             const u32 dpThreads = 64;
             const size_t traceLds = (size_t)traceRows * dpThreads * 4;
             const u32 groupLds = groupDpLdsBytes(dpLen);
+            HIP_CHECK(hipStreamWaitEvent(ctx->side[2], ctx->evFork, 0));
             hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
             hipLaunchKernelGGL(k_finalize_t<BlockGroup>, dim3(hugeBlocks), dim3(1024), 0, ctx->side[0], fa, blockMin + 1, 0xFFFFFFFFu, finWaves);
             hipLaunchKernelGGL(k_finalize_t<WaveGroup>, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa, 0u, blockMin, 0u);
             if (splitWide) hipLaunchKernelGGL(k_finalize_small_group, dim3(1024), dim3(256), 16 * groupLds, ctx->side[1], fa, smallWideList, smallWideCount, groupLds);
-            HIP_CHECK(hipEventRecord(ctx->evJoin[0], ctx->side[0]));
-            HIP_CHECK(hipEventRecord(ctx->evJoin[1], ctx->side[1]));
-            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, st, fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount, dpWideList, dpWideCount);
-            if (splitWide) hipLaunchKernelGGL(k_align_group, dim3(1024), dim3(256), 16 * groupLds, st, fa, dpWideList, dpWideCount, groupLds);
-            hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, st, fa, ctx->dpList.as<u32>(), dpCount);
-            HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[0], 0));
-            HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[1], 0));
+            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, ctx->side[2], fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount, dpWideList, dpWideCount);
+            if (splitWide) hipLaunchKernelGGL(k_align_group, dim3(1024), dim3(256), 16 * groupLds, ctx->side[2], fa, dpWideList, dpWideCount, groupLds);
+            hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, ctx->side[2], fa, ctx->dpList.as<u32>(), dpCount);
+            for (int q = 0; q < 3; ++q) HIP_CHECK(hipEventRecord(ctx->evJoin[q], ctx->side[q]));
+            // (Measured and dropped: starting a deferred sweep of the NEXT batch here, on the main stream, beside the three chains — a few hundred
+            // wavefronts that spend ~0.2 ms on per-wave latency.  5.099 vs 5.088 ms per step: the sweep's half a million workgroups win the
+            // dispatch, the chains run in its tail like every other kernel queued beside a sweep.)
+            for (int q = 0; q < 3; ++q) HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[q], 0));
         }
         else
         {
@@ -921,7 +924,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
             {"ibf_kernel", &t.ibfKernel, 0, 3}, {"ibf_slack", &t.ibfSlack, 0, 255}, {"ibf_own_stream", &t.ibfOwnStream, 0, 1},
-            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1}, {"sweep_chunk", &t.sweepChunk, 1024, 2097151}, {"async_map", &t.asyncMap, 0, 1},
+            {"pool_cap", &t.poolCap, 0, 0xFFFFFFF0ull}, {"dp_small_blocks", &t.dpSmallBlocks, 64, 65536}, {"dp_align_blocks", &t.dpAlignBlocks, 64, 65536}, {"items_sorted", &t.itemsSorted, 0, 1}, {"sweep_chunk", &t.sweepChunk, 0, 2097151}, {"async_map", &t.asyncMap, 0, 1},
         };
         for (auto & k : keys)
             if (!strcmp(k.name, key))
@@ -1322,7 +1325,7 @@ static void sweepChunk(dy_ctx * ctx, u32 maxReads)
 {
     PendingSweep & P = ctx->pending;
     if (!P.reads || P.next >= P.reads->n) return;
-    const u32 count = std::min<u32>(maxReads ? maxReads : (u32)ctx->tune.sweepChunk, P.reads->n - P.next);
+    const u32 count = std::min<u32>(maxReads ? maxReads : (u32)std::max<u64>(ctx->tune.sweepChunk, 1024), P.reads->n - P.next);
     SweepTiming & T = ctx->sweepTiming[P.slot];
     const bool timed = T.nChunks < SweepTiming::MAX_CHUNKS;
     if (timed) HIP_CHECK(hipEventRecord(T.ev[2 * T.nChunks], ctx->stream));
@@ -1353,7 +1356,7 @@ static void collectDeferredSweepTime(dy_ctx * ctx)
 // the host is about to wait for what it has just queued on the stream (a small fetch): a chunk of the pending sweep goes behind it first
 static void fetchSync(dy_ctx * ctx)
 {
-    if (ctx->pending.reads && ctx->pending.next < ctx->pending.reads->n)
+    if (ctx->tune.sweepChunk && ctx->pending.reads && ctx->pending.next < ctx->pending.reads->n)
     {
         HIP_CHECK(hipEventRecord(ctx->evFetch, ctx->stream));
         sweepChunk(ctx, 0);

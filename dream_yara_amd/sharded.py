@@ -176,6 +176,8 @@ class ShardedMapper:
         self.row2 = dy.shard_c2_row_bytes(n_bins)
         self.stream = torch.cuda.ExternalStream(ctx.stream()) if device != "cpu" else None
         self.prefetch = bool(prefetch)
+        if self.prefetch:
+            ctx.set_tuning("sweep_chunk", 16384)         # chunks of the next sweep in front of the host's waits (count fetches, peers)
         # with a deferred sweep at hand, a chunk of it sized to the transfer runs beside each all-to-all(v) (default: when there are peers to wait for)
         self.overlap_transfers = (world > 1) if overlap_transfers is None else bool(overlap_transfers)
         with self._on_stream():

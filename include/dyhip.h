@@ -57,7 +57,8 @@ void       *dy_ctx_stream(dy_ctx *ctx);
  * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next
  * batch's sweep can be queued before the current batch is mapped), dp_small_blocks (64-65536, 4096) and dp_align_blocks (64-65536, 8192: grids of the
  * thread-level aggregation / alignment kernels), items_sorted (0-1, 1: work list as (bin, read) pairs + stable radix sort; 0 = bin-major
- * count matrix), sweep_chunk (1024-2097151, 16384: reads per chunk of a deferred sweep), async_map (0-1, 0: 1 = single-end batches after a context's
+ * count matrix), sweep_chunk (0-2097151, 0: reads per chunk of a deferred sweep queued in front of every host wait; 0 = none, the sweep
+ * runs whole when its masks are first needed), async_map (0-1, 0: 1 = single-end batches after a context's
  * first are queued whole — work list and pool sized from bounds, real sizes read on the device, one fetch at the end; measured slower than waiting for
  * the two sizes), pool_cap (initial raw-match
  * pool capacity, 0 = automatic; the pool grows and the extension is re-run on overflow).  Stands where the reference has
@@ -116,11 +117,11 @@ void dy_reads_free(dy_reads *r);
  * threshold 0 reproduces the reference's "every read to every bin" (src/d_mapper.h:320-333) without the duplicate pass. */
 int  dy_ibf_query(dy_ibf *f, dy_reads *reads, uint16_t threshold, uint64_t *bin_masks_host);
 
-/* The same sweep, DEFERRED: for the batch a caller maps NEXT.  A sweep holds every wave slot of the device, so nothing can run beside it;
- * what it can hide are the host's waits inside the mapping of the CURRENT batch (for a count the host must read, for a peer rank).
- * The library queues the pending sweep chunk by chunk (tuning key sweep_chunk, reads per chunk, default 16384) in front of each of its
- * own waits, and whatever is left when the masks are first needed (dy_map_reads, dy_shard_c1_pack, ...).  One pending sweep per
- * context; the caller must not need the previous masks of `reads` any more.  Stands where the reference lets a prefetch thread load
+/* The same sweep, DEFERRED: for the batch a caller maps NEXT.  A sweep holds every wave slot of the device, so a kernel queued beside it on
+ * another stream only runs in its tail; what a sweep CAN fill are the host's waits inside the mapping of the CURRENT batch (for a count the
+ * host must read, for a peer rank): with the tuning key sweep_chunk set, a chunk of that many reads is queued in front of each wait.
+ * Whatever is left runs when the masks are first needed (dy_map_reads, dy_shard_c1_pack, ...).  One pending sweep per context; the caller
+ * must not need the previous masks of `reads` any more.  Stands where the reference lets a prefetch thread load
  * the next reads while the current batch is mapped (src/file_prefetched.h:140; src/d_mapper.h:868-887 loop). */
 int  dy_ibf_query_deferred(dy_ibf *f, dy_reads *reads, uint16_t threshold);
 /* Queues one chunk of the pending deferred sweep (max_reads reads, 0 = the default chunk) on the context's stream: for a caller that

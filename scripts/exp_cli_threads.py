@@ -8,7 +8,7 @@ import bench
 from dream_yara_amd.dist import Group
 
 class A: pass
-args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"
+args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"; args.pipeline = "off"
 s = bench.Setup("config2", args, Group(None))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 wl = s.wl; L = wl["L"]

@@ -8,7 +8,7 @@ import bench
 from dream_yara_amd.dist import Group
 import dream_yara_amd as dy
 class A: pass
-args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"
+args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"; args.pipeline = "off"
 s = bench.Setup("config2", args, Group(None))
 codes, offs = s.host_batch0
 n, L = 1_000_000, 100

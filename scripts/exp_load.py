@@ -7,7 +7,7 @@ import bench
 from dream_yara_amd.dist import Group
 import dream_yara_amd as dy
 class A: pass
-args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"
+args = A(); args.work_dir = "/tmp/dy_bench_%d" % os.getuid(); args.tune = []; args.prefetch = "off"; args.pipeline = "off"
 s = bench.Setup(sys.argv[1] if len(sys.argv) > 1 else "config2", args, Group(None))
 fpath = os.path.join(s.work_dir, "cli.filter"); s.ibf.save(fpath)
 idx_dir, bins = s.idx_dir, s.wl["bins"]

@@ -503,7 +503,7 @@ def test_batches_queued_whole_equal_the_waiting_way(dy, ob, small_filter):
         c.close()
 
 
-@pytest.mark.parametrize("chunk", [1024, 16384])
+@pytest.mark.parametrize("chunk", [0, 1024, 16384])
 def test_deferred_sweep_gives_the_same_masks_and_results(dy, ob, small_filter, chunk):
     """dy_ibf_query_deferred: the sweep of the batch mapped next is queued chunk by chunk in front of the host's waits of the current
     mapping, the rest when its masks are first needed.  Two batches alternate three times; every result equals the plain sequence
