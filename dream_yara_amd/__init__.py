@@ -95,6 +95,7 @@ SYMBOLS = [
     ("dy_result_sam", C.c_int, [_P, _P, _P, C.c_char_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("dy_reads_select_all_bins", C.c_int, [_P, _P, C.c_uint32]),
     ("dy_suffix_array", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P]),
+    ("dy_fm_build", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, _P, _P, _P, _P, C.POINTER(C.c_uint64), _P, _P, _P]),
     ("dy_index_load", C.c_int, [_P, C.c_char_p, C.c_uint32, C.POINTER(_P)]),
     ("dy_index_bins", C.c_uint32, [_P]),
     ("dy_index_contigs", C.c_uint32, [_P]),

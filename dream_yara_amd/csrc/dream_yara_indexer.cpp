@@ -1,8 +1,9 @@
 // dream_yara_indexer — builds the per-bin index files (reference src/d_indexer.cpp:127-225,389-473).
 //   dream_yara_indexer [-v] [-t THREADS] -o <OUTPUT PREFIX DIR/> <0.fna> <1.fna> ...
-// File names must be the bin number (reference src/d_indexer.cpp:178-190).  The suffix array of every bin is sorted on the GPU
-// (dy_suffix_array) when a device is visible — one context, the bins' host work spread over the -t threads around it — and by the
-// host sorter otherwise (`--sorter host` forces it); the files are byte-identical either way.
+// File names must be the bin number (reference src/d_indexer.cpp:178-190).  With a device visible the FM construction of every bin runs on it
+// (dy_fm_build: suffix array, BWT, rank dictionary, sentinel rows, sampled suffix array) — one context, the bins' host work (FASTA, N
+// randomisation, file writing) spread over the -t threads around it; `--sorter sa` keeps only the suffix sort there, `--sorter host` nothing;
+// the files are byte-identical every way.
 #include "../../include/dyhip.h"
 #include "host_index_build.hpp"
 #include <iostream>
@@ -27,7 +28,7 @@ int main(int argc, char ** argv)
             else if (a == "-t" || a == "--threads") threads = (unsigned)std::stoul(value());
             else if (a == "-td" || a == "--tmp-dir") value();
             else if (a == "-v" || a == "--verbose") verbose = true;
-            else if (a == "--sorter") { sorterName = value(); if (sorterName != "auto" && sorterName != "host" && sorterName != "gpu") throw IoError("--sorter takes auto, host or gpu"); }
+            else if (a == "--sorter") { sorterName = value(); if (sorterName != "auto" && sorterName != "host" && sorterName != "gpu" && sorterName != "sa") throw IoError("--sorter takes auto, host, gpu or sa"); }
             else if (a.size() > 1 && a[0] == '-') throw IoError("unknown option " + a);
             else
             {
@@ -45,8 +46,8 @@ int main(int argc, char ** argv)
         // the device sorter: one context shared by the worker threads (one sort at a time; the rest of a bin's work overlaps with it)
         dy_ctx * ctx = nullptr;
         std::mutex gpuMutex;
-        if (sorterName != "host" && (dy_device_count() > 0 || sorterName == "gpu"))
-            if (dy_ctx_create(0, &ctx) != DY_OK) { if (sorterName == "gpu") throw IoError(dy_last_error()); ctx = nullptr; }
+        if (sorterName != "host" && (dy_device_count() > 0 || sorterName == "gpu" || sorterName == "sa"))
+            if (dy_ctx_create(0, &ctx) != DY_OK) { if (sorterName != "auto") throw IoError(dy_last_error()); ctx = nullptr; }
         SuffixSorter sorter;
         if (ctx)
             sorter = [&](const std::vector<u32> & text, u32 sigma) {
@@ -55,7 +56,20 @@ int main(int argc, char ** argv)
                 if (dy_suffix_array(ctx, text.data(), text.size(), sigma, sa.data()) != DY_OK) throw IoError(dy_last_error());
                 return sa;
             };
-        if (verbose) std::cerr << "suffix sorting: " << (ctx ? "device 0" : "host") << "\n";
+        // with a device the whole FM construction of a bin runs there (dy_fm_build: suffix array, BWT, rank dictionary, sentinel rows, sampled
+        // suffix array); `--sorter sa` keeps only the suffix sort on the device (the round-2 split), the files are byte-identical every way
+        FmBuilder fmBuilder;
+        if (ctx && sorterName != "sa")
+            fmBuilder = [&](const std::vector<u32> & text, u32 nContigs, const std::vector<u32> & starts, BuiltBin & B) {
+                const size_t n = text.size(), idBytes = nContigs <= 255 ? 1 : 2;
+                B.drv.assign((n + 63) / 64 * 32, 0); B.ind.assign((n + 31) / 32 * 8, 0); B.val.assign((n / 10 + nContigs + 64) * (idBytes + 4), 0); B.drp.assign(nContigs, 0);
+                uint64_t nVal = 0;
+                std::lock_guard<std::mutex> g(gpuMutex);
+                if (dy_fm_build(ctx, text.data(), n, nContigs, starts.data(), B.drv.data(), B.ind.data(), B.val.data(), &nVal, B.drp.data(), B.pst, &B.drs) != DY_OK)
+                    throw IoError(dy_last_error());
+                B.val.resize((size_t)nVal * (idBytes + 4));
+            };
+        if (verbose) std::cerr << "index construction: " << (fmBuilder ? "device 0" : ctx ? "suffix sort on device 0, the rest on the host" : "host") << "\n";
         std::atomic<size_t> next(0);
         std::string firstError;
         std::mutex errMutex;
@@ -67,7 +81,7 @@ int main(int argc, char ** argv)
                 try
                 {
                     if (verbose) { std::lock_guard<std::mutex> g(errMutex); std::cerr << "[bin " << work[k].first << "] Building reference index ...\n"; }
-                    saveBin(buildBin(readFasta(work[k].second), sorter), outPrefix + std::to_string(work[k].first));
+                    saveBin(buildBin(readFasta(work[k].second), sorter, fmBuilder), outPrefix + std::to_string(work[k].first));
                 }
                 catch (std::exception const & e) { std::lock_guard<std::mutex> g(errMutex); if (firstError.empty()) firstError = e.what(); }
             }

@@ -1440,6 +1440,49 @@ int dy_ctx_background_chunk(dy_ctx * ctx, uint32_t max_reads)
     });
 }
 
+// suffix array of text[0, n) on the device: returns the buffer that holds it (one of idxA / idxB) — shared by dy_suffix_array and dy_fm_build
+struct SaBuffers { DevBuf dText, keysA, keysB, idxA, idxB, rank, flags, tmp, ties; };
+static u32 * suffixArrayOnDevice(dy_ctx * ctx, const uint32_t * text, u32 N, uint32_t sigma, SaBuffers & B)
+{
+        hipStream_t st = ctx->stream;
+        u32 bits = 1; while ((1ull << bits) <= sigma) ++bits;              // symbols are shifted by +1
+        const u32 q = 63 / bits;
+        B.dText.reserve((size_t)N * 4); B.keysA.reserve((size_t)N * 8); B.keysB.reserve((size_t)N * 8); B.idxA.reserve((size_t)N * 4); B.idxB.reserve((size_t)N * 4);
+        B.rank.reserve((size_t)N * 4); B.flags.reserve((size_t)N * 4); B.ties.reserve(64);
+        HIP_CHECK(hipMemcpyAsync(B.dText.p, text, (size_t)N * 4, hipMemcpyHostToDevice, st));
+        const dim3 grid((N + 255) / 256), block(256);
+        hipLaunchKernelGGL(k_sa_first_keys, grid, block, 0, st, B.dText.as<u32>(), N, bits, q, B.keysA.as<u64>(), B.idxA.as<u32>());
+        size_t sortBytes = 0, scanBytes = 0;
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, B.keysA.as<u64>(), B.keysB.as<u64>(), B.idxA.as<u32>(), B.idxB.as<u32>(), (int)N, 0, 64, st));
+        HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, scanBytes, B.flags.as<u32>(), B.flags.as<u32>(), MaxU32(), (int)N, st));
+        B.tmp.reserve(std::max(sortBytes, scanBytes) + 64);
+        ctx->hostStatus.reserve(64);
+        int keyBits = (int)std::min<u32>(64, q * bits);
+        // A round = sort by (rank, rank + h), regroup.  Whether a round left ties is known on the device; the host looks every round for the
+        // first two (a random genome is done after one or two) and then only every other round: a round too many only re-sorts unique keys.
+        u32 round = 0;
+        for (u32 h = q;; h = h > 0x40000000u ? 0x80000000u : h * 2, ++round)
+        {
+            size_t sb = sortBytes;
+            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(B.tmp.p, sb, B.keysA.as<u64>(), B.keysB.as<u64>(), B.idxA.as<u32>(), B.idxB.as<u32>(), (int)N, 0, keyBits, st));
+            HIP_CHECK(hipMemsetAsync(B.ties.p, 0, 4, st));
+            hipLaunchKernelGGL(k_sa_group_flags, grid, block, 0, st, B.keysB.as<u64>(), N, B.flags.as<u32>(), B.ties.as<u32>());
+            if (round < 2 || (round & 1))
+            {
+                HIP_CHECK(hipMemcpyAsync(ctx->hostStatus.p, B.ties.p, 4, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (*ctx->hostStatus.as<u32>() == 0 || h >= N) break;       // all ranks unique (h >= n cannot happen with sentinel-terminated texts)
+            }
+            size_t cb = scanBytes;
+            HIP_CHECK(hipcub::DeviceScan::InclusiveScan(B.tmp.p, cb, B.flags.as<u32>(), B.flags.as<u32>(), MaxU32(), (int)N, st));
+            hipLaunchKernelGGL(k_sa_scatter_ranks, grid, block, 0, st, B.idxB.as<u32>(), B.flags.as<u32>(), N, B.rank.as<u32>());
+            hipLaunchKernelGGL(k_sa_doubled_keys, grid, block, 0, st, B.rank.as<u32>(), N, h, B.keysA.as<u64>(), B.idxA.as<u32>());
+            keyBits = 64;
+        }
+        HIP_CHECK(hipGetLastError());
+        return B.idxB.as<u32>();
+}
+
 int dy_suffix_array(dy_ctx * ctx, const uint32_t * text, uint64_t n, uint32_t sigma, uint32_t * sa_out)
 {
     return guarded([&] {
@@ -1448,40 +1491,66 @@ int dy_suffix_array(dy_ctx * ctx, const uint32_t * text, uint64_t n, uint32_t si
         if (sigma == 0 || sigma > 0x40000000u) throw DyError(DY_EINVAL, "dy_suffix_array: alphabet size out of range");
         if (!n) return;
         HIP_CHECK(hipSetDevice(ctx->device));
+        SaBuffers B;
+        const u32 * sa = suffixArrayOnDevice(ctx, text, (u32)n, sigma, B);
+        HIP_CHECK(hipMemcpyAsync(sa_out, sa, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+int dy_fm_build(dy_ctx * ctx, const uint32_t * text, uint64_t n, uint32_t n_contigs, const uint32_t * starts, uint8_t * drv_out, uint8_t * ind_out, uint8_t * val_out,
+                uint64_t * n_val, uint32_t * drp_out, uint32_t * pst_out, uint8_t * drs_out)
+{
+    return guarded([&] {
+        if (!ctx || !text || !starts || !drv_out || !ind_out || !val_out || !n_val || !drp_out || !pst_out || !drs_out) throw DyError(DY_EINVAL, "dy_fm_build: NULL argument");
+        if (n == 0 || n >= 0x7FFFFFF0ull) throw DyError(DY_EUNSUPPORTED, "dy_fm_build: texts of 2^31 symbols or more are not supported");
+        if (n_contigs == 0 || n_contigs > 65535 || starts[0] != 0 || starts[n_contigs] != n) throw DyError(DY_EINVAL, "dy_fm_build: contig starts must run from 0 to n (1..65535 contigs)");
+        HIP_CHECK(hipSetDevice(ctx->device));
         hipStream_t st = ctx->stream;
         const u32 N = (u32)n;
-        u32 bits = 1; while ((1ull << bits) <= sigma) ++bits;              // symbols are shifted by +1
-        const u32 q = 63 / bits;
-        DevBuf dText, keysA, keysB, idxA, idxB, rank, flags, tmp, ties;
-        dText.reserve((size_t)N * 4); keysA.reserve((size_t)N * 8); keysB.reserve((size_t)N * 8); idxA.reserve((size_t)N * 4); idxB.reserve((size_t)N * 4);
-        rank.reserve((size_t)N * 4); flags.reserve((size_t)N * 4); ties.reserve(64);
-        HIP_CHECK(hipMemcpyAsync(dText.p, text, (size_t)N * 4, hipMemcpyHostToDevice, st));
-        const dim3 grid((N + 255) / 256), block(256);
-        hipLaunchKernelGGL(k_sa_first_keys, grid, block, 0, st, dText.as<u32>(), N, bits, q, keysA.as<u64>(), idxA.as<u32>());
-        size_t sortBytes = 0, scanBytes = 0;
-        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortBytes, keysA.as<u64>(), keysB.as<u64>(), idxA.as<u32>(), idxB.as<u32>(), (int)N, 0, 64, st));
-        HIP_CHECK(hipcub::DeviceScan::InclusiveScan(nullptr, scanBytes, flags.as<u32>(), flags.as<u32>(), MaxU32(), (int)N, st));
-        tmp.reserve(std::max(sortBytes, scanBytes) + 64);
-        int keyBits = (int)std::min<u32>(64, q * bits);
-        for (u32 h = q;; h = h > 0x40000000u ? 0x80000000u : h * 2)
-        {
-            size_t sb = sortBytes;
-            HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, sb, keysA.as<u64>(), keysB.as<u64>(), idxA.as<u32>(), idxB.as<u32>(), (int)N, 0, keyBits, st));
-            HIP_CHECK(hipMemsetAsync(ties.p, 0, 4, st));
-            hipLaunchKernelGGL(k_sa_group_flags, grid, block, 0, st, keysB.as<u64>(), N, flags.as<u32>(), ties.as<u32>());
-            u32 nTies = 0;
-            HIP_CHECK(hipMemcpyAsync(&nTies, ties.p, 4, hipMemcpyDeviceToHost, st));
-            HIP_CHECK(hipStreamSynchronize(st));
-            if (nTies == 0 || h >= N) break;                                // all ranks unique (h >= n cannot happen with sentinel-terminated texts)
-            size_t cb = scanBytes;
-            HIP_CHECK(hipcub::DeviceScan::InclusiveScan(tmp.p, cb, flags.as<u32>(), flags.as<u32>(), MaxU32(), (int)N, st));
-            hipLaunchKernelGGL(k_sa_scatter_ranks, grid, block, 0, st, idxB.as<u32>(), flags.as<u32>(), N, rank.as<u32>());
-            hipLaunchKernelGGL(k_sa_doubled_keys, grid, block, 0, st, rank.as<u32>(), N, h, keysA.as<u64>(), idxA.as<u32>());
-            keyBits = 64;
-        }
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(sa_out, idxB.p, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+        SaBuffers B;
+        const u32 * sa = suffixArrayOnDevice(ctx, text, N, n_contigs + 4, B);
+        const u32 nBlocks = (N + 63) / 64, nEntries = (N + 31) / 32, idBytes = n_contigs <= 255 ? 1u : 2u;
+        DevBuf dStarts, sym, sampled, occ, counts, before, drv, bitsA, cntA, bitsZ, cntZ, beforeA, beforeZ, ind, val, drp;
+        dStarts.reserve((size_t)(n_contigs + 1) * 4 + 64); sym.reserve(N + 64); sampled.reserve(N + 64); occ.reserve(64);
+        counts.reserve((size_t)(nBlocks + 1) * sizeof(Count4) + 64); before.reserve((size_t)(nBlocks + 1) * sizeof(Count4) + 64); drv.reserve((size_t)nBlocks * 32 + 64);
+        for (DevBuf * d : {&bitsA, &cntA, &bitsZ, &cntZ, &beforeA, &beforeZ}) d->reserve((size_t)(nEntries + 1) * 4 + 64);
+        ind.reserve((size_t)nEntries * 8 + 64); val.reserve(((size_t)N / 10 + n_contigs + 64) * (idBytes + 4)); drp.reserve((size_t)n_contigs * 4 + 64);
+        HIP_CHECK(hipMemcpyAsync(dStarts.p, starts, (size_t)(n_contigs + 1) * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync(occ.p, 0, 32, st));
+        hipLaunchKernelGGL(k_fm_rows, dim3((N + 255) / 256), dim3(256), 0, st, sa, B.dText.as<u32>(), N, n_contigs, dStarts.as<u32>(), sym.as<u8>(), sampled.as<u8>(), occ.as<u32>());
+        u32 hostOcc[5];
+        HIP_CHECK(hipMemcpyAsync(hostOcc, occ.p, 20, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
+        if (hostOcc[4] != n_contigs) throw DyError(DY_EINVAL, "dy_fm_build: the text does not hold one sentinel per contig");
+        u32 drs = 0;
+        for (u32 c = 1; c < 4; ++c) if (hostOcc[c] < hostOcc[drs]) drs = c;          // least frequent symbol stands in for the sentinels (gold: SURVEY.md A.3)
+        pst_out[0] = n_contigs; pst_out[1] = pst_out[0] + hostOcc[0]; pst_out[2] = pst_out[1] + hostOcc[1]; pst_out[3] = pst_out[2] + hostOcc[2]; pst_out[4] = N;
+        *drs_out = (u8)drs;
+        hipLaunchKernelGGL(k_fm_block_counts, dim3((nBlocks + 1 + 255) / 256), dim3(256), 0, st, sym.as<u8>(), N, drs, nBlocks, counts.as<Count4>());
+        {
+            size_t tb = 0; Count4 zero; zero.c[0] = zero.c[1] = zero.c[2] = zero.c[3] = 0;
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb, counts.as<Count4>(), before.as<Count4>(), Count4Sum(), zero, (int)(nBlocks + 1), st));
+            ctx->scanTmp.reserve(tb + 64);
+            HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(ctx->scanTmp.p, tb, counts.as<Count4>(), before.as<Count4>(), Count4Sum(), zero, (int)(nBlocks + 1), st));
+        }
+        hipLaunchKernelGGL(k_fm_drv, dim3((nBlocks + 255) / 256), dim3(256), 0, st, sym.as<u8>(), N, drs, nBlocks, before.as<Count4>(), drv.as<u8>());
+        hipLaunchKernelGGL(k_fm_bit_words, dim3((nEntries + 1 + 255) / 256), dim3(256), 0, st, sym.as<u8>(), sampled.as<u8>(), N, nEntries, bitsA.as<u32>(), cntA.as<u32>(),
+                           bitsZ.as<u32>(), cntZ.as<u32>());
+        exclusiveSum(ctx, cntA.as<u32>(), beforeA.as<u32>(), (size_t)nEntries + 1);
+        exclusiveSum(ctx, cntZ.as<u32>(), beforeZ.as<u32>(), (size_t)nEntries + 1);
+        hipLaunchKernelGGL(k_fm_samples, dim3((nEntries + 255) / 256), dim3(256), 0, st, sa, N, n_contigs, dStarts.as<u32>(), nEntries, bitsA.as<u32>(), beforeA.as<u32>(),
+                           bitsZ.as<u32>(), beforeZ.as<u32>(), ind.as<u8>(), val.as<u8>(), idBytes, drp.as<u32>());
+        HIP_CHECK(hipGetLastError());
+        u32 nSamples = 0;
+        HIP_CHECK(hipMemcpyAsync(&nSamples, beforeA.as<u32>() + nEntries, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipMemcpyAsync(drv_out, drv.p, (size_t)nBlocks * 32, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(ind_out, ind.p, (size_t)nEntries * 8, hipMemcpyDeviceToHost, st));
+        if (nSamples) HIP_CHECK(hipMemcpyAsync(val_out, val.p, (size_t)nSamples * (idBytes + 4), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(drp_out, drp.p, (size_t)n_contigs * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        *n_val = nSamples;
     });
 }
 

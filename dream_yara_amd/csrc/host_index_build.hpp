@@ -108,7 +108,11 @@ struct BuiltBin
 
 // `sorter` (optional): suffix array of (text, alphabet size) — the device sort of libdyhip when the indexer runs on a GPU box
 typedef std::function<std::vector<u32>(const std::vector<u32> &, u32)> SuffixSorter;
-inline BuiltBin buildBin(const std::vector<FastaRecord> & recs, const SuffixSorter & sorter = SuffixSorter())
+// `fmBuilder` (optional): everything behind the text — suffix array, BWT, rank dictionary, sentinel rows, sampled suffix array — into B
+// (dy_fm_build of libdyhip: the whole FM construction on the device); it takes precedence over `sorter`
+struct BuiltBin;
+typedef std::function<void(const std::vector<u32> & text, u32 nContigs, const std::vector<u32> & starts, BuiltBin & B)> FmBuilder;
+inline BuiltBin buildBin(const std::vector<FastaRecord> & recs, const SuffixSorter & sorter = SuffixSorter(), const FmBuilder & fmBuilder = FmBuilder())
 {
     BuiltBin B;
     B.count = recs.size();
@@ -146,6 +150,7 @@ inline BuiltBin buildBin(const std::vector<FastaRecord> & recs, const SuffixSort
         }
         start[cnt] = p;
     }
+    if (fmBuilder) { fmBuilder(T, cnt, start, B); return B; }
     std::vector<u32> sa = sorter ? sorter(T, cnt + 4) : suffixArrayDoubling(T, cnt + 4);
 
     // row -> (contig, offset); BWT with the sentinel substitute; sentinel rows

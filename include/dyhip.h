@@ -157,6 +157,16 @@ void dy_index_free(dy_index *idx);
  * compare equal), built on the device.  Stands where the reference lets SeqAn construct the FM index of a bin's reversed contigs
  * (reference src/d_indexer.cpp:278-333); BWT, rank dictionary and the sampled suffix array follow from it on the host. */
 int  dy_suffix_array(dy_ctx *ctx, const uint32_t *text, uint64_t n, uint32_t sigma, uint32_t *sa_out);
+/* The FM index arrays of one bin, built on the device from the same kind of text: contig c reversed with its Ns randomised, as symbols
+ * n_contigs + base, followed by its sentinel symbol c; starts[c] = first position of contig c (n_contigs + 1 entries, the last = n).
+ * Suffix array (as dy_suffix_array), then BWT, symbol counts, the rank dictionary blocks, the sentinel rows and the sampled suffix array
+ * in the layouts of the reference's files (reference src/d_indexer.cpp:278-333 builds them inside SeqAn, the
+ * sampling rate 10 is YaraFMConfig's, src/misc_types.h:151-177).  Host outputs, caller-allocated: drv_out ((n+63)/64 x 32 B = lf.drv),
+ * ind_out ((n+31)/32 x 8 B = sa.ind), val_out (room for n/10 + n_contigs + 64 records of 5 B, or 6 B above 255 contigs = sa.val; *n_val
+ * records are written), drp_out (n_contigs rows, ascending: lf.drp up to 255 contigs, the set bits of its dictionary above),
+ * pst_out[5] (lf.pst), *drs_out (lf.drs). */
+int  dy_fm_build(dy_ctx *ctx, const uint32_t *text, uint64_t n, uint32_t n_contigs, const uint32_t *starts, uint8_t *drv_out, uint8_t *ind_out, uint8_t *val_out,
+                 uint64_t *n_val, uint32_t *drp_out, uint32_t *pst_out, uint8_t *drs_out);
 
 /* ---- mapping ----------------------------------------------------------------------------------------- */
 typedef struct {

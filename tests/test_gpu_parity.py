@@ -1319,9 +1319,11 @@ def test_bins_with_more_than_255_contigs_match_oracle(dy, ctx, ob, tmp_path, n_c
 
 
 def test_gpu_indexer_reproduces_gold_bytes_and_the_host_sorter(product_build, dy, ctx, tmp_path):
-    """dream_yara_indexer sorts the suffixes of every bin on the device (dy_suffix_array: prefix doubling over hipcub radix
-    sorts).  The 768 files it writes for the 64 gold genomes are the gold files byte for byte; on texts that need many doubling rounds
-    (a 30 kbp homopolymer run, planted repeats, 300 short contigs with their sentinels) the device's suffix array equals the host sorter's."""
+    """dream_yara_indexer builds the FM index of every bin on the device (dy_fm_build: suffix array by prefix doubling over hipcub
+    radix sorts, then BWT, rank dictionary blocks, sentinel rows and the sampled suffix array).  The 768 files it writes for the 64 gold
+    genomes are the gold files byte for byte — also with only the suffix sort on the device (`--sorter sa`); on texts that need many doubling
+    rounds (a 30 kbp homopolymer run, planted repeats) and on a bin of 301 contigs (u16 contig ids, sentinel rows as a Levels dictionary)
+    device, suffix-sort-only and host builds write the same bytes."""
     import filecmp
     names, codes, offs = read_fasta_codes(GENOMES_FA)
     fa_dir = tmp_path / "fa"; fa_dir.mkdir()
@@ -1331,11 +1333,17 @@ def test_gpu_indexer_reproduces_gold_bytes_and_the_host_sorter(product_build, dy
     out = tmp_path / "idx"; out.mkdir()
     log = subprocess.run([os.path.join(product_build, "dream_yara_indexer"), "-v", "--sorter", "gpu", "-t", "8", "-o", str(out) + "/"] +
                          [str(fa_dir / ("%d.fna" % b)) for b in range(64)], check=True, capture_output=True, text=True).stderr
-    assert "suffix sorting: device 0" in log
+    assert "index construction: device 0" in log
     files = sorted(os.listdir(GOLD_INDEX))
     assert len(files) == 768
     for n in files:
         assert filecmp.cmp(os.path.join(GOLD_INDEX, n), str(out / n), shallow=False), n
+    out2 = tmp_path / "idx_sa"; out2.mkdir()
+    log = subprocess.run([os.path.join(product_build, "dream_yara_indexer"), "-v", "--sorter", "sa", "-t", "8", "-o", str(out2) + "/"] +
+                         [str(fa_dir / ("%d.fna" % b)) for b in range(0, 64, 7)], check=True, capture_output=True, text=True).stderr
+    assert "suffix sort on device 0" in log
+    for n in sorted(os.listdir(out2)):
+        assert filecmp.cmp(os.path.join(GOLD_INDEX, n), str(out2 / n), shallow=False), n
     # many doubling rounds: homopolymer run + repeats; many sentinels
     rng = np.random.default_rng(5)
     g = rng.integers(0, 4, 200000, dtype=np.uint8)
@@ -1347,10 +1355,14 @@ def test_gpu_indexer_reproduces_gold_bytes_and_the_host_sorter(product_build, dy
         for i in range(300):
             c = rng.integers(0, 4, int(rng.integers(30, 120)), dtype=np.uint8)
             f.write(b">c%d\n" % i + np.frombuffer(b"ACGTN", np.uint8)[c].tobytes() + b"\n")
+    c3 = tmp_path / "c3"; c3.mkdir()
     subprocess.check_call([os.path.join(product_build, "dream_yara_indexer"), "--sorter", "gpu", "-o", str(a) + "/", str(tmp_path / "0.fna")])
     subprocess.check_call([os.path.join(product_build, "dream_yara_indexer"), "--sorter", "host", "-o", str(b) + "/", str(tmp_path / "0.fna")])
+    subprocess.check_call([os.path.join(product_build, "dream_yara_indexer"), "--sorter", "sa", "-o", str(c3) + "/", str(tmp_path / "0.fna")])
+    assert len(os.listdir(a)) == 12
     for n in sorted(os.listdir(a)):
         assert filecmp.cmp(str(a / n), str(b / n), shallow=False), n
+        assert filecmp.cmp(str(a / n), str(c3 / n), shallow=False), n
     # the ABI entry on its own: two sequences with their sentinels
     text = np.array([2 + 1, 2 + 0, 2 + 1, 2 + 0, 0, 2 + 0, 2 + 1, 1], dtype=np.uint32)       # "CACA$0 AC$1" over {$0,$1,A,C,G,T}
     sa = dy.suffix_array(ctx, text, 6)
