@@ -236,7 +236,8 @@ class Setup:
             index = sm.index
         else:
             index = dy.Index(ctx, self.idx_dir, wl["bins"])
-        log("rank %d: %s [%s]: index uploaded in %.1f s" % (rank, self.name, mode, time.time() - t_load))
+        info = index.info()
+        log("rank %d: %s [%s]: index uploaded in %.1f s (q-mer table: q = %d, %.1f GB)" % (rank, self.name, mode, time.time() - t_load, info["prefix_q"], info["bytes_prefix_table"] / 1e9))
         info = index.info()
         batches, params, thr = self.batches, self.params, self.thr
 

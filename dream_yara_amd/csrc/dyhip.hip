@@ -116,6 +116,7 @@ struct Tuning
 {
     u64 sparseSa = 0;           // 1 = keep the on-disk SA sampling (no expanded SA)
     u64 prefixQ = 12;           // q of the q-mer range table (0 = none); capped by the free HBM at load
+    u64 prefixWide = 1;         // 16-byte table entries that carry the bases after a unique q-mer (k_prefix_wide), when they fit
     u64 noIsa = 0;              // 1 = no inverse SA / indexed text (pure LF walk)
     u64 finalizeBlockMin = 2048;// reads with more raw matches are aggregated by a 1024-thread block
     u64 finalizeNoKeys = 0;     // 1 = block aggregation sorts indices instead of 128-bit keys
@@ -296,8 +297,8 @@ struct dy_index
     std::vector<BinDesc> bins;
     std::vector<std::string> contigNames;
     std::vector<u64> contigLengths;
-    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable, isa, ftext;
-    bool hasIsa = false;
+    DevBuf dBins, rank, ind, valOffset, valContig, contigs, limits, drp, saFullOffset, saFullContig, prefixTable, prefixWide, isa, ftext;
+    bool hasIsa = false, hasWide = false;
     bool hasFullSa = false, multiContig = false, sharded = false;
     mutable DevBuf dNames, dNameOffs; mutable bool namesOnDevice = false;      // contig names for dy_result_sam (uploaded at the first use)
     std::vector<u64> ownedMask;     // bins whose FM structures are resident (all of them unless loaded sharded)
@@ -310,7 +311,8 @@ struct dy_index
         v.valContig = valContig.as<u16>(); v.contigs = contigs.as<u8>(); v.limits = limits.as<u64>(); v.drp = drp.as<u32>();
         v.saFullOffset = hasFullSa ? saFullOffset.as<u32>() : nullptr;
         v.saFullContig = (hasFullSa && multiContig) ? saFullContig.as<u16>() : nullptr;
-        v.prefixTable = prefixQ ? prefixTable.as<uint2>() : nullptr; v.prefixQ = prefixQ;
+        v.prefixTable = (prefixQ && !hasWide) ? prefixTable.as<uint2>() : nullptr; v.prefixQ = prefixQ;
+        v.prefixWide = (prefixQ && hasWide) ? prefixWide.as<uint4>() : nullptr;
         v.isa = hasIsa ? isa.as<u32>() : nullptr; v.ftext = hasIsa ? ftext.as<u8>() : nullptr;
         v.nBins = (u32)bins.size();
         return v;
@@ -919,7 +921,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
         if (!ctx || !key) throw DyError(DY_EINVAL, "dy_ctx_set_tuning: NULL argument");
         Tuning & t = ctx->tune;
         const struct { const char * name; u64 * slot; u64 lo, hi; } keys[] = {
-            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"no_isa", &t.noIsa, 0, 1},
+            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"no_isa", &t.noIsa, 0, 1},
             {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
@@ -1670,6 +1672,25 @@ static int loadIndex(dy_ctx * ctx, const char * dir, uint32_t n_bins, const uint
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipStreamSynchronize(ctx->stream));
             }
+            // 16-byte entries with the bases after each unique q-mer, when twice the table still leaves three quarters of the free HBM
+            HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+            u32 nOwned = 0;
+            for (u32 b = 0; b < n_bins; ++b) nOwned += idx->bins[b].n ? 1 : 0;
+            const size_t wideBytes = ((size_t)std::max(nOwned, 1u) << (2 * idx->prefixQ)) * sizeof(uint4);
+            if (ctx->tune.prefixWide && wideBytes < freeB / 4)
+            {
+                idx->prefixWide.reserveExact(wideBytes + 64);
+                IndexView v3 = idx->view();
+                const u32 nEntries = 1u << (2 * idx->prefixQ);
+                for (u32 b = 0; b < n_bins; ++b)
+                    if (idx->bins[b].n)
+                        hipLaunchKernelGGL(k_prefix_wide, dim3((nEntries + 255) / 256), dim3(256), 0, ctx->stream, v3, b,
+                                           idx->prefixTable.as<uint2>() + idx->bins[b].prefixOff, idx->prefixWide.as<uint4>() + idx->bins[b].prefixOff, nEntries);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                idx->hasWide = true;
+                DevBuf drop; idx->prefixTable.moveTo(drop);           // the narrow table is not read again
+            }
         }
         *out = idx.release();
     });
@@ -1696,7 +1717,7 @@ int dy_index_get_info(const dy_index * idx, dy_index_info * info)
     info->n_bins_resident = resident; info->total_rows = rows;
     info->bytes_rank = idx->rank.cap; info->bytes_sparse_sa = idx->ind.cap + idx->valOffset.cap + idx->valContig.cap; info->bytes_contigs = idx->contigs.cap;
     info->bytes_expanded_sa = idx->hasFullSa ? idx->saFullOffset.cap + idx->saFullContig.cap : 0;
-    info->bytes_prefix_table = idx->prefixQ ? idx->prefixTable.cap : 0;
+    info->bytes_prefix_table = idx->prefixQ ? (idx->hasWide ? idx->prefixWide.cap : idx->prefixTable.cap) : 0;
     info->bytes_isa_and_text = idx->hasIsa ? idx->isa.cap + idx->ftext.cap : 0;
     return DY_OK;
 }

@@ -22,6 +22,8 @@ struct IndexView
     const u32 *     saFullOffset;   // expanded SA (one entry per BWT row) or nullptr: then the sparse SA is walked
     const u16 *     saFullContig;   // nullptr when every bin has a single contig
     const uint2 *   prefixTable;    // per bin 4^q (lo,hi) ranges of every q-mer, or nullptr
+    const uint4 *   prefixWide;     // the same table in 16-byte entries {lo, hi, next bases 0-15, next bases 16-31} (k_prefix_wide), or nullptr;
+                                    // when it exists it REPLACES prefixTable
     const u32 *     isa;            // inverse of the expanded SA: row of the suffix at (contig, offset in the reversed contig), or nullptr
     const u8 *      ftext;          // the INDEXED text (Ns randomised), forward, laid out like `contigs`; position 0 of a contig is undefined
     u32             prefixQ;
@@ -40,7 +42,7 @@ struct BinView
     const u32 *   saFullOffset;
     const u16 *   saFullContig;
     u32 n, nContigs, drs;
-    u32 pst[4];
+    uint4 pst;                  // C[A..T]; read through sel4: a dynamically indexed array would put the whole view into scratch memory
 };
 
 __device__ __forceinline__ BinView makeBinView(const IndexView & ix, u32 bin)
@@ -57,7 +59,7 @@ __device__ __forceinline__ BinView makeBinView(const IndexView & ix, u32 bin)
     b.saFullOffset = ix.saFullOffset ? ix.saFullOffset + d.saFullOff : nullptr;
     b.saFullContig = ix.saFullContig ? ix.saFullContig + d.saFullOff : nullptr;
     b.n = d.n; b.nContigs = d.nContigs; b.drs = d.drs;
-    b.pst[0] = d.pst[0]; b.pst[1] = d.pst[1]; b.pst[2] = d.pst[2]; b.pst[3] = d.pst[3];
+    b.pst = make_uint4(d.pst[0], d.pst[1], d.pst[2], d.pst[3]);
     return b;
 }
 
@@ -92,7 +94,7 @@ __device__ __forceinline__ u32 lfMap(const BinView & b, u32 pos, u32 c)
     uint4 sym = blk[0], cnt = blk[1];
     u32 r = sel4(cnt, c) + countInBlock(sym, c, pos & 63);
     if (c == b.drs) r -= sentinelsBefore(b, pos);
-    return b.pst[c] + r;
+    return sel4(b.pst, c) + r;
 }
 
 __device__ __forceinline__ u32 bwtSymbol(const BinView & b, u32 row)
@@ -120,8 +122,8 @@ __device__ __forceinline__ bool fmStep(const BinView & b, u32 & lo, u32 & hi, u3
     u32 rl = sel4(cntLo, c) + countInBlock(symLo, c, lo & 63);
     u32 rh = sel4(cntHi, c) + countInBlock(symHi, c, hi & 63);
     if (c == b.drs) { rl -= sentinelsBefore(b, lo); rh -= sentinelsBefore(b, hi); }
-    lo = b.pst[c] + rl;
-    hi = b.pst[c] + rh;
+    lo = sel4(b.pst, c) + rl;
+    hi = sel4(b.pst, c) + rh;
     return lo < hi;
 }
 
@@ -219,6 +221,35 @@ __global__ void k_prefix_direct(IndexView ix, u32 bin, uint2 * __restrict__ tabl
     u32 contig, x;
     fmLocate(b, r.x, contig, x);
     table[i] = make_uint2(x, DIRECT_QMER | contig);
+}
+
+// 8 bytes of 2-bit codes -> 16 bits, byte j in bits 2j..2j+1 (the caller has checked that every byte is < 4, or masks the result)
+__device__ __forceinline__ u32 pack2bit8(u64 w)
+{
+    w &= 0x0303030303030303ull;
+    w = (w | (w >> 6)) & 0x000F000F000F000Full;
+    w = (w | (w >> 12)) & 0x000000FF000000FFull;
+    return (u32)((w | (w >> 24)) & 0xFFFFu);
+}
+
+// The q-mer table in 16-byte entries: a unique q-mer also carries the (up to) 32 bases that FOLLOW its one occurrence in the indexed text,
+// two bits each, so K2 verifies the rest of a seed from the table's own cache line instead of a second miss in the text.
+// Bases past the contig's end stay 0: a seed that needs them starts before the contig does and K2 rejects it on x < rem first.
+__global__ void k_prefix_wide(IndexView ix, u32 bin, const uint2 * __restrict__ narrow, uint4 * __restrict__ wide, u32 nEntries)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nEntries) return;
+    const uint2 r = narrow[i];
+    if (r.y < DIRECT_QMER) { wide[i] = make_uint4(r.x, r.y, 0u, 0u); return; }
+    const u32 contig = r.y & 0xFFFFu, x = r.x;
+    const u64 * limits = ix.limits + ix.bins[bin].limOff;
+    const u64 lim = limits[contig];
+    const u32 clen = (u32)(limits[contig + 1] - lim);
+    const u8 * text = ix.ftext + ix.bins[bin].contigOff + lim + (clen - x);
+    u64 next = 0;
+    const u32 have = min(x, 32u);
+    for (u32 j = 0; j < have; ++j) next |= (u64)(text[j] & 3u) << (2 * j);
+    wide[i] = make_uint4(r.x, r.y, (u32)next, (u32)(next >> 32));
 }
 
 __global__ void k_expand_sa(IndexView ix, u32 bin, u32 * __restrict__ outOffset, u16 * __restrict__ outContig)

@@ -339,6 +339,8 @@ __global__ void k_items_scatter(const u64 * __restrict__ masks, u32 nReads, u32 
     }
 }
 
+// K2 compiles to 74 registers = 6 waves per SIMD.  Capping it at 64 registers for 8 waves (the LF walk then spills 28 bytes per lane) was
+// slower, 0.547 ms against 0.484 ms per 1 M reads: the kernel waits on ~20 random 64-byte DRAM accesses per read, not on latency.
 // ---------------------------------------------------------------------------------------------------
 // K2: exact search of the round-0 seeds. One thread per (item, strand, seed slot).
 // hits0[item * 2*S0 + strand*S0 + seedId] = (lo, hi); seedId k covers read offset (count-1-k)*len
@@ -366,10 +368,10 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
     {
         const u32 seedLen = len / cnt, off = (cnt - 1 - seedId) * seedLen;
         const u32 bin = itemBin[item];
-        BinView b = makeBinView(ix, bin);
-        u32 lo = 0, hi = b.n, d0 = 0;
+        // the bin's view (~25 registers) is only built on the paths that walk the FM index: the table paths need the contig limits at most
+        u32 lo = 0, hi = ix.bins[bin].n, d0 = 0;
         bool ok = true;
-        if (ix.prefixTable && seedLen >= ix.prefixQ)
+        if ((ix.prefixTable || ix.prefixWide) && seedLen >= ix.prefixQ)
         {   // first q characters through the q-mer table
             // the seed is contiguous in the strand's own array (seqsRc holds the reverse complements): 8 bases per load
             u32 idx = 0;
@@ -385,12 +387,45 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
             d0 = ix.prefixQ;
             if (ok)
             {
-                const uint2 r = ix.prefixTable[ix.bins[bin].prefixOff + idx];
+                uint2 r; u64 next = 0;
+                if (ix.prefixWide)
+                {
+                    const uint4 e = ix.prefixWide[ix.bins[bin].prefixOff + idx];
+                    r = make_uint2(e.x, e.y); next = e.z | ((u64)e.w << 32);
+                }
+                else r = ix.prefixTable[ix.bins[bin].prefixOff + idx];
+                if (r.y >= DIRECT_QMER && ix.prefixWide && seedLen - d0 <= 32)
+                {   // the q-mer occurs once and the entry holds its position AND the bases that follow it: the rest of the seed is compared
+                    // two bits a base against the entry itself (no second miss in the indexed text)
+                    const u32 rem = seedLen - d0, contig = r.y & 0xFFFFu, x = r.x;
+                    uint2 hit = make_uint2(0u, 0u);
+                    if (x >= rem)                                                // else the seed would start before the contig does
+                    {
+                        const u8 * pat = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off + d0;
+                        u64 w[4] = {0, 0, 0, 0};
+#pragma unroll
+                        for (u32 k = 0; k < 4; ++k) if (rem > 8 * k) w[k] = load8(pat + 8 * k);
+                        u64 p = 0, bad = 0;
+#pragma unroll
+                        for (u32 k = 0; k < 4; ++k)
+                        {
+                            if (rem <= 8 * k) continue;
+                            const u32 nb = min(8u, rem - 8 * k);
+                            bad |= w[k] & 0xFCFCFCFCFCFCFCFCull & (~0ull >> (8 * (8 - nb)));          // an N never matches
+                            p |= (u64)pack2bit8(w[k]) << (16 * k);
+                        }
+                        const u64 cmp = rem ? (p ^ next) & (~0ull >> (64 - 2 * rem)) : 0ull;
+                        if (!bad && !cmp) hit = make_uint2(x - rem, DIRECT_HIT | contig);
+                    }
+                    hits0[(size_t)item * slots + slot] = hit;
+                    return;
+                }
                 if (r.y >= DIRECT_QMER)
                 {   // the q-mer occurs once and the table holds its position: compare the rest of the seed with the indexed text
                     const u32 rem = seedLen - d0, contig = r.y & 0xFFFFu, x = r.x;
-                    const u64 lim = b.limits[contig];
-                    const u32 clen = (u32)(b.limits[contig + 1] - lim);
+                    const u64 * limits = ix.limits + ix.bins[bin].limOff;
+                    const u64 lim = limits[contig];
+                    const u32 clen = (u32)(limits[contig + 1] - lim);
                     uint2 hit = make_uint2(0u, 0u);
                     if (x >= rem)                                                // else the seed would start before the contig does
                     {
@@ -409,6 +444,7 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
                 const u8 * pat = (strand ? rd.seqsRc : rd.seqs) + rd.offs[read] + off + d0;
                 const u8 * ftext = ix.ftext + ix.bins[bin].contigOff;
                 const u32 * isa = ix.isa + ix.bins[bin].saFullOff;
+                const BinView b = makeBinView(ix, bin);
                 u32 found = 0, first = 0xFFFFFFFFu, oneX = 0, oneContig = 0;
                 for (u32 row = lo; row < hi; ++row)
                 {
@@ -429,10 +465,14 @@ __global__ __launch_bounds__(256) void k_seed_search(IndexView ix, ReadsView rd,
                 return;
             }
         }
-        for (u32 d = d0; d < seedLen && ok; ++d)
+        if (ok && d0 < seedLen)
         {
-            u32 c = readBase(seq, len, strand, off + d);
-            ok = c < 4 && fmStep(b, lo, hi, c);          // N never matches (reference src/index_fm.h:147)
+            const BinView b = makeBinView(ix, bin);
+            for (u32 d = d0; d < seedLen && ok; ++d)
+            {
+                u32 c = readBase(seq, len, strand, off + d);
+                ok = c < 4 && fmStep(b, lo, hi, c);          // N never matches (reference src/index_fm.h:147)
+            }
         }
         if (ok) res = make_uint2(lo, hi);
     }

@@ -51,7 +51,8 @@ int         dy_ctx_sync(dy_ctx *ctx);
 /* Returns the context's hipStream_t as an opaque pointer (for event timing by the caller). */
 void       *dy_ctx_stream(dy_ctx *ctx);
 /* Selects among result-identical code paths / device-only tables of a context (the library never reads the environment).
- * Keys (value range, default): sparse_sa (0-1, 0), prefix_q (0-12, 12), no_isa (0-1, 0) — read by dy_index_load;
+ * Keys (value range, default): sparse_sa (0-1, 0), prefix_q (0-12, 12), prefix_wide (0-1, 1: 16-byte q-mer table
+ * entries that carry the bases following a unique q-mer, when they fit), no_isa (0-1, 0) — read by dy_index_load;
  * finalize_block_min (>=1, 2048), finalize_no_keys (0-1, 0), pe_heavy_min (>=1, 256), pe_rescue_global (0-1, 0),
  * ibf_narrow (0-1, 0), ibf_full_tail (0-1, 0), ibf_lds_kb (4-60, 12), ibf_dense (0-1, 0), ibf_kernel (0-3, 0: sweep for more than 64 bins chosen from the filter fill; 1 lazy, 2 eager2, 3 wide),
  * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next
