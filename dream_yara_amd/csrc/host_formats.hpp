@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <dlfcn.h>
 #ifdef DY_HAVE_ZLIB
 #include <zlib.h>
 #endif
@@ -352,10 +353,57 @@ struct ReadsBatch
     }
 };
 
+// bzip2 streams through the system's libbz2.so.1.0, bound at run time (the image carries the library but not its header; the three entry
+// points and bz_stream below are bzip2 1.0's documented, frozen ABI).  Concatenated streams (pbzip2) are decoded one after the other.
+inline void bunzip2Into(const u8 * in, size_t nIn, std::vector<u8> & out, const std::string & path)
+{
+    struct BzStream
+    {
+        char * next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+        char * next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+        void * state; void * (*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void * opaque;
+    };
+    enum { BZ_OK = 0, BZ_STREAM_END = 4 };
+    void * lib = dlopen("libbz2.so.1.0", RTLD_NOW);
+    if (!lib) lib = dlopen("libbz2.so.1", RTLD_NOW);
+    if (!lib) throw IoError("bzip2-compressed input needs libbz2.so.1.0 on this system");
+    auto init = (int (*)(BzStream *, int, int))dlsym(lib, "BZ2_bzDecompressInit");
+    auto step = (int (*)(BzStream *))dlsym(lib, "BZ2_bzDecompress");
+    auto done = (int (*)(BzStream *))dlsym(lib, "BZ2_bzDecompressEnd");
+    if (!init || !step || !done) { dlclose(lib); throw IoError("libbz2 lacks the BZ2_bzDecompress entry points"); }
+    std::vector<u8> chunk(1 << 22);
+    size_t at = 0;
+    while (at < nIn)
+    {
+        BzStream z;
+        memset(&z, 0, sizeof(z));
+        if (init(&z, 0, 0) != BZ_OK) { dlclose(lib); throw IoError("libbz2 could not start a stream"); }
+        int rc = BZ_OK;
+        while (rc == BZ_OK)
+        {
+            if (z.avail_in == 0 && at < nIn)
+            {
+                const size_t take = std::min<size_t>(nIn - at, 1u << 30);
+                z.next_in = (char *)in + at; z.avail_in = (unsigned)take; at += take;
+            }
+            z.next_out = (char *)chunk.data(); z.avail_out = (unsigned)chunk.size();
+            const unsigned inBefore = z.avail_in;
+            rc = step(&z);
+            const size_t got = chunk.size() - z.avail_out;
+            out.insert(out.end(), chunk.begin(), chunk.begin() + got);
+            if (rc == BZ_OK && got == 0 && z.avail_in == inBefore && at >= nIn) rc = -7;      // truncated: no progress and no input left
+        }
+        at -= z.avail_in;                              // what the stream did not consume belongs to the next one
+        done(&z);
+        if (rc != BZ_STREAM_END) { dlclose(lib); throw IoError("corrupt bzip2 stream in " + path); }
+    }
+    dlclose(lib);
+}
+
 class ReadsFile
 {
 public:
-    // plain or gzip-compressed FASTA/FASTQ (reference src/d_mapper.cpp:120-138 accepts .gz through SeqAn's stream layer);
+    // plain, gzip- or bzip2-compressed FASTA/FASTQ (reference src/d_mapper.cpp:120-138 accepts .gz / .bz2 through SeqAn's stream layer);
     // a compressed file is inflated into memory once
     explicit ReadsFile(const std::string & path) : map_(path), p_(map_.data()), end_(map_.data() + map_.size())
     {
@@ -379,7 +427,10 @@ public:
 #endif
         }
         else if (map_.size() >= 3 && map_.data()[0] == 'B' && map_.data()[1] == 'Z' && map_.data()[2] == 'h')
-            throw IoError("bzip2-compressed input is not supported (no libbz2 on this system)");
+        {
+            bunzip2Into(map_.data(), map_.size(), inflated_, path);
+            p_ = inflated_.data(); end_ = inflated_.data() + inflated_.size();
+        }
     }
     // Reads up to maxReads records into b; returns their number.  Byte spans of the mapped file, no temporaries:
     //   * four-line FASTQ (the usual case) with several threads: the threads index the line ends of a window sized from the previous

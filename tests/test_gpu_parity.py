@@ -989,8 +989,8 @@ def _write_fastq(path, codes, offs, lo, hi, suffix):
 
 
 def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
-    """-o x.bam gives a valid BGZF/BAM whose decoded records equal the SAM run; gzip-compressed reads give the same output."""
-    import gzip, shutil
+    """-o x.bam gives a valid BGZF/BAM whose decoded records equal the SAM run; gzip- and bzip2-compressed reads give the same output."""
+    import bz2, gzip, shutil
     exe = os.path.join(product_build, "dream_yara_mapper")
     sam, bam, sam_gz = str(tmp_path / "o.sam"), str(tmp_path / "o.bam"), str(tmp_path / "ogz.sam")
     gz_reads = str(tmp_path / "reads.fa.gz")
@@ -1000,6 +1000,11 @@ def test_cli_bam_output_and_gzip_input(product_build, small_filter, tmp_path):
     subprocess.check_call(base + [READS_FA, "-o", sam])
     subprocess.check_call(base + [READS_FA, "-o", bam])
     subprocess.check_call(base + [gz_reads, "-o", sam_gz])
+    bz_reads, sam_bz = str(tmp_path / "reads.fa.bz2"), str(tmp_path / "obz.sam")
+    with open(READS_FA, "rb") as fi, open(bz_reads, "wb") as fo:
+        fo.write(bz2.compress(fi.read()))
+    subprocess.check_call(base + [bz_reads, "-o", sam_bz])
+    assert sam_records(sam_bz) == sam_records(sam)
     sam_lines = [l.rstrip("\n") for l in open(sam)]
     text, refs, recs, n_blocks = bam_to_sam_lines(bam)
     hdr = [l for l in sam_lines if l.startswith("@")]

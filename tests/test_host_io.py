@@ -1,4 +1,4 @@
-"""Host-side I/O of dream_yara_mapper without a GPU: the FASTA/FASTQ/gzip parser and the SAM / BGZF-BAM writers
+"""Host-side I/O of dream_yara_mapper without a GPU: the FASTA/FASTQ/gzip/bzip2 parser and the SAM / BGZF-BAM writers
 (dream_yara_amd/csrc/host_formats.hpp, bam_writer.hpp) through a small harness compiled here with g++."""
 import gzip
 import os
@@ -13,7 +13,7 @@ from conftest import ROOT, bam_to_sam_lines
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("hostio") / "host_io_harness")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-DDY_HAVE_ZLIB", "-o", exe,
-                           os.path.join(ROOT, "tests", "host", "host_io_harness.cpp"), "-lz"])
+                           os.path.join(ROOT, "tests", "host", "host_io_harness.cpp"), "-lz", "-ldl"])
     return exe
 
 
@@ -34,6 +34,14 @@ def test_reads_parser_handles_fasta_fastq_gzip_and_odd_lines(harness, tmp_path):
     with gzip.open(gz, "wb") as f:
         f.write(fq.read_bytes())
     assert subprocess.check_output([harness, "parse", str(gz), "1"]) == subprocess.check_output([harness, "parse", str(fq), "1000"])
+    import bz2
+    bz = tmp_path / "a.fq.bz2"
+    raw = fq.read_bytes()
+    bz.write_bytes(bz2.compress(raw[:40]) + bz2.compress(raw[40:]))          # two concatenated streams, as pbzip2 writes them
+    assert subprocess.check_output([harness, "parse", str(bz), "2"]) == subprocess.check_output([harness, "parse", str(fq), "1000"])
+    cut = tmp_path / "cut.fq.bz2"
+    cut.write_bytes(bz2.compress(raw * 50)[:-20])
+    assert subprocess.call([harness, "parse", str(cut), "10"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
     bad = tmp_path / "bad.txt"
     bad.write_text("hello\n")
     assert subprocess.call([harness, "parse", str(bad), "10"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 1
