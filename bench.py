@@ -300,7 +300,7 @@ class Setup:
                                "by two packed all-to-alls over RCCL%s" % (world, ", next sweep queued in chunks in front of the host's waits" if sm.prefetch else "")),
                "items_per_read": items / wl["reads"], "raw_matches_per_read": raws / wl["reads"],
                "stage_ms_per_step": {k: v / steps for k, v in stage_ms.items()},
-               "ibf_kernel": dy.IBF_KERNEL_NAMES.get(st["ibf_kernel"]), "ibf_first_check_slack": st["ibf_slack"], "ibf_tail_pre": st["ibf_tail_pre"],
+               "ibf_kernel": dy.IBF_KERNEL_NAMES.get(st["ibf_kernel"]), "ibf_first_check_slack": st["ibf_slack"], "ibf_tail_pre": st["ibf_tail_pre"], "extend_second_pass_items": st["second_pass_items"],
                "device_tables": {"resident_bins": info["n_bins_resident"], "bwt_rows": info["total_rows"],
                                  "reference_structures_bytes": {"rank_dictionary": info["bytes_rank"], "sparse_sa": info["bytes_sparse_sa"], "contigs_unpacked": info["bytes_contigs"]},
                                  "device_only_bytes": {"expanded_sa": info["bytes_expanded_sa"], "qmer_range_table_q%d" % info["prefix_q"]: info["bytes_prefix_table"],
@@ -402,6 +402,7 @@ class Setup:
                "reads_per_gpu_per_step": self.wl["reads"], "batches_per_step": self.n_batches, "resident_batches": self.n_resident, "parallelism": leg["parallelism"],
                "mapped_fraction": float(mapped.mean()), "primary_in_true_bin": float((rr["primary"]["contig"][mapped] == truth[mapped]).mean()),
                "items_per_read": leg["items_per_read"], "raw_matches_per_read": leg["raw_matches_per_read"],
+               "extend_second_pass_items_per_read": leg["extend_second_pass_items"] / max(1, self.per_batch),
                "stage_ms_per_step": leg["stage_ms_per_step"], "device_tables": leg["device_tables"]}
         if self.paired:
             cfg["paired_fraction"] = float(rr["paired"].mean())

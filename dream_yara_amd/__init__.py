@@ -47,7 +47,7 @@ class ReadResult(C.Structure):
 class MapStats(C.Structure):
     _fields_ = [("items", C.c_uint64), ("raw_matches", C.c_uint64), ("hard_items", C.c_uint64), ("pool_retries", C.c_uint64),
                 ("ms_ibf", C.c_double), ("ms_items", C.c_double), ("ms_search", C.c_double), ("ms_extend", C.c_double),
-                ("ms_finalize", C.c_double), ("ibf_kernel", C.c_uint32), ("ibf_slack", C.c_uint32), ("ibf_tail_pre", C.c_uint32), ("reserved", C.c_uint32)]
+                ("ms_finalize", C.c_double), ("ibf_kernel", C.c_uint32), ("ibf_slack", C.c_uint32), ("ibf_tail_pre", C.c_uint32), ("second_pass_items", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):

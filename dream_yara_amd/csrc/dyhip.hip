@@ -104,7 +104,7 @@ int deviceCount()
 
 } // namespace
 
-// ctx->counters (u32 slots, zeroed before K3): 0 unused, 1 pool overflow flag, 2 items of the wavefront-per-item list, 3 complex reads,
+// ctx->counters (u32 slots, zeroed before K3): 0 items k_extend's fast pass left to the full form, 1 pool overflow flag, 2 items of the wavefront-per-item list, 3 complex reads,
 // 4 align list, 5 small list, 6 DP list / rescue jobs, 7 bad raw record (dy_finalize_raw), 8 PE child list, 9 PE align list, 10 PE small list,
 // 11 PE heavy pairs, 12 busy-but-not-re-seeded items (= slot 2 + 10, see extendEasyItem), 13 inconsistent record met by k_group_matches,
 // 14-15 the 64-bit raw-match count, 16 small list / 17 DP list of the wide bands (a match with more than 3 errors)
@@ -116,6 +116,7 @@ struct Tuning
 {
     u64 sparseSa = 0;           // 1 = keep the on-disk SA sampling (no expanded SA)
     u64 prefixQ = 12;           // q of the q-mer range table (0 = none); capped by the free HBM at load
+    u64 extendMode = 1;         // K3: 1 fast pass + a second launch over the listed rest (k_extend MODE 1 + 0), 0 fast pass + the block's own rest in full (MODE 2), 2 one full pass (MODE 0)
     u64 prefixWide = 1;         // 16-byte table entries that carry the bases after a unique q-mer (k_prefix_wide), when they fit
     u64 noIsa = 0;              // 1 = no inverse SA / indexed text (pure LF walk)
     u64 finalizeBlockMin = 2048;// reads with more raw matches are aggregated by a 1024-thread block
@@ -161,7 +162,7 @@ struct dy_ctx
     DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shLen, shLenOff, shOwner, shTotals, hardList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
+           shLen, shLenOff, shOwner, shTotals, hardList, slowList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
     size_t poolCap = 0;
     DevBuf devItems;                    // u32[4]: [0] the work list's size as the kernels see it, [1] as counted, [2] it did not fit (k_items_clamp)
     double itemsPerRead = 0.0;          // of the last batch mapped: sizes the next batch's work list when nothing waits for its count
@@ -376,8 +377,23 @@ __global__ void k_fill_masks(u64 * masks, u32 nReads, u32 W, u32 nBins)
 template <int NW>
 static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & rv, u32 nItems, u32 S0, const MapParams & mp, const MatchSink & sink, u32 maxSeedLen)
 {
-    hipLaunchKernelGGL(k_extend<NW>, dim3(((nItems + 255) / 256 + 7) / 8 * 8), dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
-                       ctx->devItemCount, S0, mp, ctx->hits0.as<uint2>(), sink, ctx->counters.as<u32>() + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>());
+    const dim3 grid(((nItems + 255) / 256 + 7) / 8 * 8);
+    u32 * counters = ctx->counters.as<u32>();
+    const u32 mode = mp.sensitivity == 2 ? 2u : (u32)ctx->tune.extendMode;          // -y full: edit-distance seeds, no fast pass (tuning extend_mode)
+    if (mode == 0)          // fast pass, then each block redoes what it left (counters[0]: how many items that was)
+        hipLaunchKernelGGL((k_extend<NW, 2>), grid, dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                           ctx->devItemCount, S0, mp, ctx->hits0.as<uint2>(), sink, counters + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>(), counters, (u32 *)nullptr, 1u);
+    else if (mode == 1)
+    {   // fast pass, then the listed rest in a launch of its own (counters[0] = its size; the second grid covers the worst case, the
+        // blocks the list does not need return at once)
+        hipLaunchKernelGGL((k_extend<NW, 1>), grid, dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                           ctx->devItemCount, S0, mp, ctx->hits0.as<uint2>(), sink, counters + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>(), counters, ctx->slowList.as<u32>(), 1u);
+        hipLaunchKernelGGL((k_extend<NW, 0>), grid, dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                           counters, S0, mp, ctx->hits0.as<uint2>(), sink, counters + 2, ctx->hardList.as<u32>(), ctx->slowList.as<u32>(), (u32 *)nullptr, (u32 *)nullptr, 0u);
+    }
+    else
+        hipLaunchKernelGGL((k_extend<NW, 0>), grid, dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
+                           ctx->devItemCount, S0, mp, ctx->hits0.as<uint2>(), sink, counters + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>(), (u32 *)nullptr, (u32 *)nullptr, 1u);
     // re-seeded items: list-driven, spread thinly over a full grid (normally a tiny fraction of the items)
     // -y full: the edit-distance trie walk keeps one frame per level in a slab, one slice per wavefront of this grid
     const u32 hardBlocks = 2048;
@@ -580,6 +596,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         ctx->counters.reserve(COUNTER_BYTES);
         ctx->readMatchCount.reserve((size_t)(nReads + 1) * 4);
         ctx->hardList.reserve((size_t)nItems * 4 + 64);
+        ctx->slowList.reserve((size_t)nItems * 4 + 64);
         if (ctx->tune.poolCap) { if (!ctx->poolCap) ctx->poolCap = (size_t)ctx->tune.poolCap; }
         else if (ctx->poolCap < (size_t)nItems + 1024) ctx->poolCap = (size_t)nItems * 2 + 1024;
         u32 hostCounters[COUNTER_BYTES / 4] = {0};   // layout: see COUNTER_* below
@@ -621,7 +638,7 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         const u32 nPool = async ? (u32)std::min<size_t>(ctx->poolCap, 0xFFFFFFF0u) : (u32)poolTotal;
         if (!async)
         {
-            ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12];     // re-seeded items, as the reference counts them
+            ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12]; ctx->stats.second_pass_items = hostCounters[0];     // re-seeded items, as the reference counts them
             if (nReads) ctx->itemsPerRead = std::max(0.25, (double)nItems / (double)nReads);
         }
         nItemsOut = nItems; nPoolOut = nPool;
@@ -921,7 +938,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
         if (!ctx || !key) throw DyError(DY_EINVAL, "dy_ctx_set_tuning: NULL argument");
         Tuning & t = ctx->tune;
         const struct { const char * name; u64 * slot; u64 lo, hi; } keys[] = {
-            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"no_isa", &t.noIsa, 0, 1},
+            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"extend_mode", &t.extendMode, 0, 2}, {"no_isa", &t.noIsa, 0, 1},
             {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},

@@ -13,6 +13,7 @@
 #include "dy_types.h"
 #include "fm_device.h"
 #include "myers_device.h"
+#include "extend_sides.h"
 
 namespace dy {
 
@@ -63,72 +64,6 @@ __global__ __launch_bounds__(256) void k_revcomp_reads(const u8 * __restrict__ f
     }
 }
 
-// ---- 8-bytes-at-a-time comparison of Dna5 code strings (N = 4 never matches, reference src/basic_alphabet.h:47) ----
-struct __attribute__((packed)) PackedU64 { u64 v; };
-__device__ __forceinline__ u64 load8(const u8 * p) { return ((const PackedU64 *)p)->v; }
-// bit 8*i set iff byte i differs or holds an N on either side
-__device__ __forceinline__ u64 mismatchFlags(u64 a, u64 b)
-{
-    u64 x = (a ^ b) | ((a | b) & 0x0404040404040404ull);
-    x |= (x >> 1) | (x >> 2);
-    return x & 0x0101010101010101ull;
-}
-// length of the common prefix of a[0..n) and b[0..n).  32 bytes per step with all eight loads issued before the first compare:
-// the loop is a chain of dependent memory round trips (the early exit keeps the compiler from hoisting loads), and K3 is bound
-// by exactly that latency.
-__device__ __forceinline__ int lcpForward(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
-{
-    int i = 0;
-    for (; i + 32 <= n; i += 32)
-    {
-        const u64 a0 = load8(a + i), a1 = load8(a + i + 8), a2 = load8(a + i + 16), a3 = load8(a + i + 24);
-        const u64 b0 = load8(b + i), b1 = load8(b + i + 8), b2 = load8(b + i + 16), b3 = load8(b + i + 24);
-        const u64 f0 = mismatchFlags(a0, b0), f1 = mismatchFlags(a1, b1), f2 = mismatchFlags(a2, b2), f3 = mismatchFlags(a3, b3);
-        if (f0) return i + (__ffsll((long long)f0) - 1) / 8;
-        if (f1) return i + 8 + (__ffsll((long long)f1) - 1) / 8;
-        if (f2) return i + 16 + (__ffsll((long long)f2) - 1) / 8;
-        if (f3) return i + 24 + (__ffsll((long long)f3) - 1) / 8;
-    }
-    for (; i + 8 <= n; i += 8)
-    {
-        const u64 f = mismatchFlags(load8(a + i), load8(b + i));
-        if (f) return i + (__ffsll((long long)f) - 1) / 8;
-    }
-    if (i < n && n >= 8)
-    {   // the last 1..7 bytes as one 8-byte chunk ending at n (its first bytes are known to be equal) instead of a round trip per byte
-        const u64 f = mismatchFlags(load8(a + n - 8), load8(b + n - 8));
-        return f ? n - 8 + (__ffsll((long long)f) - 1) / 8 : n;
-    }
-    for (; i < n; ++i) { const u32 x = a[i], y = b[i]; if (!(x == y && x < 4)) break; }
-    return i;
-}
-// length of the common suffix of a[-n..0) and b[-n..0) (a, b point one past the last byte)
-__device__ __forceinline__ int lcpBackward(const u8 * __restrict__ a, const u8 * __restrict__ b, int n)
-{
-    int i = 0;
-    for (; i + 32 <= n; i += 32)
-    {
-        const u64 a0 = load8(a - i - 8), a1 = load8(a - i - 16), a2 = load8(a - i - 24), a3 = load8(a - i - 32);
-        const u64 b0 = load8(b - i - 8), b1 = load8(b - i - 16), b2 = load8(b - i - 24), b3 = load8(b - i - 32);
-        const u64 f0 = mismatchFlags(a0, b0), f1 = mismatchFlags(a1, b1), f2 = mismatchFlags(a2, b2), f3 = mismatchFlags(a3, b3);
-        if (f0) return i + __clzll((long long)f0) / 8;
-        if (f1) return i + 8 + __clzll((long long)f1) / 8;
-        if (f2) return i + 16 + __clzll((long long)f2) / 8;
-        if (f3) return i + 24 + __clzll((long long)f3) / 8;
-    }
-    for (; i + 8 <= n; i += 8)
-    {
-        const u64 f = mismatchFlags(load8(a - i - 8), load8(b - i - 8));
-        if (f) return i + __clzll((long long)f) / 8;
-    }
-    if (i < n && n >= 8)
-    {
-        const u64 f = mismatchFlags(load8(a - n), load8(b - n));
-        return f ? n - 8 + __clzll((long long)f) / 8 : n;
-    }
-    for (; i < n; ++i) { const u32 x = a[-1 - i], y = b[-1 - i]; if (!(x == y && x < 4)) break; }
-    return i;
-}
 // mismatches of a[0..n) against b[0..n), 32 bytes per step with every load issued before the first count; there is no 8-byte / single-byte
 // tail: the chunks of the last step are CLAMPED to end at n (chunk k starts at min(i + 8k, n - 8)) and the bytes a clamped chunk re-reads
 // are masked out of its flags — K2's 13-byte verification is one round trip instead of two
@@ -487,6 +422,7 @@ struct ItemState
     // the end of the kernel (a single shared counter saturates at ~10^8 atomics/s); further matches go straight to the pool
     RawMatch buf0, buf1;
     u32 nbuf;
+    bool defer;        // k_extend's first pass only: the item needs what that pass leaves out (a third match, a full edit distance search)
 };
 
 struct MatchSink
@@ -503,9 +439,22 @@ struct MatchSink
 // `emit(matchBegin, matchLength, errors)` is called once if the occurrence extends to a match.
 // `edit` (-y full, TSeedsDistance = EditDistance, reference src/find_extender.h:314-322): no _checkSeed, and the left extension starts at
 // the seed's END, re-aligning the seed region as well.
-template <int NW, typename TEmit>
-__device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBeginSeed, u32 seedLen,
-                                                  const u8 * __restrict__ seq, u32 len, u32 needleBeginSeed, u32 maxErrors, bool edit, TEmit emit)
+//
+// FAST (the first pass of k_extend, Hamming seeds only): where an extension side stops at a mismatch, the side is closed WITHOUT the edit
+// distance search when everything after that mismatch matches — the search's answer is then known:
+//   * the mismatching pair cannot be part of an exact alignment, so no end position has distance 0; the diagonal end has distance 1;
+//   * the search keeps the LAST end position with the smallest distance: one position beyond the diagonal has distance 1 only if the
+//     needle equals the text shifted by one (the text's first character inserted) — checked with one more LCP; positions further out
+//     cost at least 2;
+//   * right side (last base held out, reference src/find_extender.h:369-395): the same with the held-out base compared at the end the
+//     search reports; if it differs on the diagonal the side has two errors and is not closed here.
+// Anything else returns EXT_NEEDS_SEARCH before a match is emitted, and the caller hands the ITEM to the second pass (FAST = false: the
+// search itself).  A wavefront runs the search loop as long as any of its lanes does, so leaving it out only pays when whole wavefronts
+// skip it: tests/native/myers_fuzz.cpp checks the closed forms against the search on random and low-complexity inputs.
+enum : u32 { EXT_DONE = 0, EXT_NEEDS_SEARCH = 1 };
+template <int NW, bool FAST, typename TEmit>
+__device__ __forceinline__ u32 extendOccurrenceT(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBeginSeed, u32 seedLen,
+                                                 const u8 * __restrict__ seq, u32 len, u32 needleBeginSeed, u32 maxErrors, bool edit, TEmit emit)
 {
     const u8 * __restrict__ ctg = binContigs + binLimits[contig];
     const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
@@ -513,7 +462,7 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
     // _checkSeed: recount against the real contig (Ns were randomised in the index); the early-out of the reference's
     // loop only matters when the total exceeds maxErrors, which fails either way
     u32 errors = edit ? 0u : countMismatches(ctg + hayBeginSeed, seq + needleBeginSeed, (int)seedLen);
-    if (errors > maxErrors) return;
+    if (errors > maxErrors) return EXT_DONE;
     // anchor of the left extension
     const u32 hayBegin = edit ? hayEnd : hayBeginSeed, needleBegin = edit ? needleEnd : needleBeginSeed;
     u32 matchBegin = hayBegin;
@@ -528,25 +477,15 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
         else
         {
             const u32 remaining = maxErrors - errors;
-            if (!remaining) return;
-            u32 minErr = remaining + 1;
-            int endPos = 0;
+            if (!remaining) return EXT_DONE;
             const u32 hb = hayBegin - 1 - lcp, nb = needleBegin - 1 - lcp;
-            // the Myers loops ask for elements 0, 1, 2, ... with a wave-uniform index: one 8-byte load serves eight of them (a
-            // byte load per column costs the texture addresser a full divergent access each time); elements whose 8-byte group
-            // would start before the array are fetched singly
-            u64 nw = 0, tw = 0;
-            auto needleAt = [&](int i) -> u32 {
-                if ((i & 7) == 0) { if (nb >= (u32)i + 7) nw = load8(seq + nb - i - 7); else { nw = 0; for (u32 t = 0; t < 8 && (u32)i + t <= nb; ++t) nw |= (u64)seq[nb - i - t] << (8 * (7 - t)); } }
-                return (u32)(nw >> (8 * (7 - (i & 7)))) & 0xff; };
-            auto textAt = [&](int j) -> u32 {
-                if ((j & 7) == 0) { if (hb >= (u32)j + 7) tw = load8(ctg + hb - j - 7); else { tw = 0; for (u32 t = 0; t < 8 && (u32)j + t <= hb; ++t) tw |= (u64)ctg[hb - j - t] << (8 * (7 - t)); } }
-                return (u32)(tw >> (8 * (7 - (j & 7)))) & 0xff; };
-            prefixSearch<NW>(needleAt, ndlLen - lcp, textAt, hayLen - lcp, (int)remaining,
-                                  [&](int pos, int dist) { if ((u32)dist <= minErr) { minErr = (u32)dist; endPos = pos + 1; } });
-            errors += minErr;
-            matchBegin -= (u32)(endPos + lcp);
-            if (errors > maxErrors) return;
+            int end = 0;
+            u32 cost = 1;
+            if (FAST) { if (!closeLeftSide(ctg, hb, seq, nb, ndlLen - lcp, hayLen - lcp, end)) return EXT_NEEDS_SEARCH; }
+            else cost = searchLeftSide<NW>(ctg, hb, seq, nb, ndlLen - lcp, hayLen - lcp, remaining, end);
+            errors += cost;
+            matchBegin -= (u32)(end + lcp);
+            if (errors > maxErrors) return EXT_DONE;
         }
     }
     u32 matchEnd = hayEnd;
@@ -563,49 +502,39 @@ __device__ __forceinline__ void extendOccurrenceT(const u8 * __restrict__ binCon
         {
             errors += (u32)(ndlLen - hayLen);
             matchEnd += lcp;
-            if (errors > maxErrors) return;
+            if (errors > maxErrors) return EXT_DONE;
         }
         else
         {
             const u32 remaining = maxErrors - errors;
-            if (!remaining) return;
-            u32 minErr = remaining + 1;
-            int endPos = 0;
+            if (!remaining) return EXT_DONE;
             const u32 hb = hayEnd + lcp, nb = needleEnd + lcp;
-            const int hl = hayLen - lcp, nl = ndlLen - lcp;
-            const u32 lastNeedle = seq[nb + nl - 1];
-            u64 nw = 0, tw = 0;        // forward: an 8-byte load may run past the needle / window, never past the padded arrays
-            auto needleAt = [&](int i) -> u32 { if ((i & 7) == 0) nw = load8(seq + nb + i); return (u32)(nw >> (8 * (i & 7))) & 0xff; };
-            auto textAt = [&](int j) -> u32 { if ((j & 7) == 0) tw = load8(ctg + hb + j); return (u32)(tw >> (8 * (j & 7))) & 0xff; };
-            prefixSearch<NW>(needleAt, nl - 1, textAt, hl - 1, (int)remaining,
-                                  [&](int pos, int dist) {
-                                      const int currentEnd = pos + 1;
-                                      u32 cur = (u32)dist;
-                                      const u32 h = ctg[hb + currentEnd];
-                                      if (!(h == lastNeedle && h < 4))
-                                          if (++cur > remaining) return;
-                                      if (cur <= minErr) { minErr = cur; endPos = currentEnd; }
-                                  });
-            errors += minErr;
-            matchEnd += (u32)(endPos + lcp + 1);
-            if (errors > maxErrors) return;
+            int end = 0;
+            u32 cost = 1;
+            if (FAST) { if (!closeRightSide(ctg, hb, seq, nb, ndlLen - lcp, hayLen - lcp, end)) return EXT_NEEDS_SEARCH; }
+            else cost = searchRightSide<NW>(ctg, hb, seq, nb, ndlLen - lcp, hayLen - lcp, remaining, end);
+            errors += cost;
+            matchEnd += (u32)(end + lcp + 1);
+            if (errors > maxErrors) return EXT_DONE;
         }
     }
     emit(matchBegin, matchEnd - matchBegin, errors);
+    return EXT_DONE;
 }
 
 // one item per lane: _addMatchImpl into the lane's ItemState
-template <int NW>
-__device__ void extendOccurrence(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
-                                 const u8 * __restrict__ seq, u32 len, u32 strand,
-                                 u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink, bool edit)
+template <int NW, bool FAST>
+__device__ u32 extendOccurrence(const u8 * __restrict__ binContigs, const u64 * __restrict__ binLimits, u32 contig, u32 hayBegin, u32 seedLen,
+                                const u8 * __restrict__ seq, u32 len, u32 strand,
+                                u32 needleBegin, u32 maxErrors, u32 read, u32 bin, ItemState & st, const MatchSink & sink, bool edit)
 {
-    extendOccurrenceT<NW>(binContigs, binLimits, contig, hayBegin, seedLen, seq, len, needleBegin, maxErrors, edit, [&](u32 matchBegin, u32 matchLen, u32 errors) {
+    return extendOccurrenceT<NW, FAST>(binContigs, binLimits, contig, hayBegin, seedLen, seq, len, needleBegin, maxErrors, edit, [&](u32 matchBegin, u32 matchLen, u32 errors) {
         RawMatch m;
         m.read = read; m.begin = matchBegin; m.len = (u16)matchLen; m.errors = (u8)errors; m.strand = (u8)strand;
         m.bin = (u16)bin; m.contig = (u16)contig;
         if (st.nbuf == 0) { st.buf0 = m; st.nbuf = 1; }
         else if (st.nbuf == 1) { st.buf1 = m; st.nbuf = 2; }
+        else if (FAST) st.defer = true;                  // the first pass never touches the pool
         else
         {
             const u64 slot = atomicAdd(sink.poolCount, 1ull);
@@ -790,11 +719,14 @@ __device__ __forceinline__ u32 classifyItem(const uint2 * __restrict__ h0, u32 S
 // Every lane walks its own (rank, strand, SA row) sequence — seeds by ascending hit count, ties keep ascending seed
 // id, forward hits before reverse hits, early exit after a rank — but the lanes meet at ONE extension call per
 // round, so the wavefront pays for max(#occurrences per lane) extensions instead of one per (rank, strand) pair.
-template <int NW>
-__device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
+// FAST: see extendOccurrenceT; returns true when the item has to be redone by the full form (nothing of it has left the lane then).
+// listHard: this call sees the item for the first time (re-seeded and busy items are listed for k_extend_hard exactly once).
+template <int NW, bool FAST>
+__device__ bool extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
                                const uint2 * __restrict__ hits0, const MatchSink & sink, u32 * __restrict__ hardCount, u32 * __restrict__ hardList,
-                               ItemState & st, bool valid)
+                               bool listHard, ItemState & st, bool valid)
 {
+    bool deferred = false;
     const u8 * seq = nullptr, * seqRc = nullptr;
     u32 len = 0, readErrors = 0, readStrata = 0, cnt0 = 1, seedErrors = 0;
     // only what the extension itself needs stays live per lane (the full BinView costs ~25 VGPRs; a row that still has to be
@@ -812,8 +744,8 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
         cnt0 = seedCountOf(readErrors, 0);
         u64 totalHits;
         seedErrors = classifyItem(h0, S0, prm, totalHits);
-        if (seedErrors == 0 && totalHits > DY_BUSY_ITEM_HITS) { seedErrors = 3; atomicAdd(hardCount + 10, 1u); }   // not re-seeded, just busy (counted apart: counters[12]); any non-zero value keeps it out of this kernel
-        if (seedErrors) hardList[atomicAdd(hardCount, 1u)] = item;          // left to k_extend_hard
+        if (seedErrors == 0 && totalHits > DY_BUSY_ITEM_HITS) { seedErrors = 3; if (listHard) atomicAdd(hardCount + 10, 1u); }   // not re-seeded, just busy (counted apart: counters[12]); any non-zero value keeps it out of this kernel
+        if (seedErrors && listHard) hardList[atomicAdd(hardCount, 1u)] = item;          // left to k_extend_hard
     }
     bool active = valid && seedErrors == 0 && len >= cnt0;
     const u32 seedLen = active ? len / cnt0 : 0;
@@ -857,10 +789,18 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
             ++row;
             const u32 clen = (u32)(binLimits[contig + 1] - binLimits[contig]);
             if (clen - x >= seedLen)
-                extendOccurrence<NW>(binContigs, binLimits, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors, read, bin, st, sink,
-                                     prm.sensitivity == 2);
+            {
+                const u32 status = extendOccurrence<NW, FAST>(binContigs, binLimits, contig, clen - x - seedLen, seedLen, strand ? seqRc : seq, len, strand, needleBegin, readErrors,
+                                                              read, bin, st, sink, FAST ? false : prm.sensitivity == 2);      // the host starts the first pass for Hamming seeds only
+                if (FAST && (status == EXT_NEEDS_SEARCH || st.defer))
+                {   // the whole item is redone by the full form: nothing of it has left the lane yet
+                    deferred = true;
+                    st.nbuf = 0; st.defer = false; active = false;
+                }
+            }
         }
     }
+    return deferred;
 }
 
 #ifndef DY_K3_WAVES
@@ -872,6 +812,29 @@ __device__ void extendEasyItem(const IndexView & ix, const ReadsView & rd, u32 i
 // done by all lanes in step and the SA rows of every leaf are dealt to the 64 lanes, each extending its own occurrence.  A rank is
 // a unit (all hits of the rank's two seeds are extended, then minErrors decides the exit), so the order inside it is free; the
 // minimum over the lanes is taken after each rank.  Matches go to the pool step by step (st's buffers stay unused).
+// the same per WAVEFRONT (no barrier: the other wavefronts of the block may have left)
+__device__ __forceinline__ void flushWaveMatches(const ItemState & st, u32 read, const MatchSink & sink, u32 lane)
+{
+    const u32 cnt = st.nbuf;
+    u32 incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += t; }
+    const u32 total = (u32)__shfl(incl, 63, 64);
+    if (!total) return;
+    u64 base = 0;
+    if (lane == 0) base = atomicAdd(sink.poolCount, (unsigned long long)total);
+    base = ((u64)__shfl((u32)(base >> 32), 0, 64) << 32) | (u32)__shfl((u32)base, 0, 64);
+    const u64 first = base + incl - cnt;
+    if (cnt >= 1)
+    {
+        if (first < sink.poolCap) { sink.pool[first] = st.buf0; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+    if (cnt >= 2)
+    {
+        if (first + 1 < sink.poolCap) { sink.pool[first + 1] = st.buf1; atomicAdd(&sink.readMatchCount[read], 1u); } else atomicExch(sink.overflow, 1u);
+    }
+}
+
 template <int NW>
 __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u32 item, u32 read, u32 bin, u32 S0, const MapParams & prm,
                                    const uint2 * __restrict__ hits0, const MatchSink & sink, ItemState & st, u32 lane, EditFrame * __restrict__ editStack)
@@ -926,7 +889,7 @@ __device__ void extendHardItemWave(const IndexView & ix, const ReadsView & rd, u
                             fmLocate(b, row, contig, x);
                             const u32 clen = (u32)(b.limits[contig + 1] - b.limits[contig]);
                             if (clen - x >= seedLen)      // suffixLength >= seedLength
-                                extendOccurrenceT<NW>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, sq, len, off, readErrors, edit,
+                                extendOccurrenceT<NW, false>(b.contigs, b.limits, contig, clen - x - seedLen, seedLen, sq, len, off, readErrors, edit,
                                                       [&](u32 matchBegin, u32 matchLen, u32 errors) { got = 1; mBegin = matchBegin; mLen = matchLen; mErrors = errors; mContig = contig; });
                         }
                         // every lane holds at most one new match of the SAME read: one pool reservation and one per-read count update per
@@ -996,24 +959,60 @@ __device__ __forceinline__ void flushBlockMatches(const ItemState & st, u32 read
     }
 }
 
-template <int NW>
+// K3 in three forms (MODE), the same raw matches from each:
+//   0  the full algorithm in one pass: every edit distance search where it arises.  A wavefront runs the search loop as long as ANY lane
+//      needs it, and nearly every wavefront holds such a lane;
+//   1  the FAST pass (extendOccurrenceT) over every item; the items it cannot finish go to slowList, which a second launch (MODE 0 with
+//      nItemsDev = the list's counter, perm = the list, listHard = 0) redoes in full;
+//   2  the FAST pass, then the block's unfinished items — compacted into its first wavefronts through LDS — redone in full by the same
+//      block: the searches run in a quarter (or less) of the wavefronts, beside other blocks' first phases instead of in a sparse launch
+//      of their own.
+template <int NW, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 2 ? DY_K3_WAVES : 1, NW <= 2 ? DY_K3_WAVES : 8))) void k_extend(IndexView ix, ReadsView rd, const u32 * __restrict__ itemRead, const u16 * __restrict__ itemBin,
                                                 const u32 * __restrict__ nItemsDev, u32 S0, MapParams prm, const uint2 * __restrict__ hits0, MatchSink sink,
-                                                u32 * __restrict__ hardCount, u32 * __restrict__ hardList, const u32 * __restrict__ perm)
+                                                u32 * __restrict__ hardCount, u32 * __restrict__ hardList, const u32 * __restrict__ perm,
+                                                u32 * __restrict__ slowCount, u32 * __restrict__ slowList, u32 listHard)
 {
     const u32 nItems = *nItemsDev;
     const u32 useful = ((nItems + 255) / 256 + 7) / 8 * 8;
     if (blockIdx.x >= useful) return;                         // uniform per block
     const u32 idx = xcdRemapBlock(blockIdx.x, useful) * blockDim.x + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
-    ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
+    ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0; st.defer = false;
     u32 read = 0;
     u32 bin = 0;
     const bool valid = idx < nItems;
     const u32 item = valid ? perm[idx] : 0;           // work order: see k_item_order_*
     if (valid) { read = itemRead[item]; bin = itemBin[item]; }
-    extendEasyItem<NW>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardCount, hardList, st, valid);
-    flushBlockMatches(st, read, sink, lane);
+    if (MODE == 0)
+    {
+        extendEasyItem<NW, false>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardCount, hardList, listHard != 0, st, valid);
+        flushBlockMatches(st, read, sink, lane);
+        return;
+    }
+    const bool deferred = extendEasyItem<NW, true>(ix, rd, item, read, bin, S0, prm, hits0, sink, hardCount, hardList, true, st, valid);
+    if (MODE == 1)
+    {
+        if (deferred) slowList[atomicAdd(slowCount, 1u)] = item;
+        flushBlockMatches(st, read, sink, lane);
+        return;
+    }
+    __shared__ u32 blockSlow[256];
+    __shared__ u32 blockSlowCount;
+    if (threadIdx.x == 0) blockSlowCount = 0;
+    __syncthreads();
+    if (deferred) blockSlow[atomicAdd(&blockSlowCount, 1u)] = item;
+    flushBlockMatches(st, read, sink, lane);                  // (its barriers also close the list)
+    const u32 nSlow = blockSlowCount;
+    if (slowCount && threadIdx.x == 0 && nSlow) atomicAdd(slowCount, nSlow);      // statistics only
+    if ((threadIdx.x & ~63u) >= nSlow) return;                // wavefronts without a listed item leave (uniform per wavefront): their slots go to other blocks
+    const bool valid2 = threadIdx.x < nSlow;
+    const u32 item2 = valid2 ? blockSlow[threadIdx.x] : 0;
+    u32 read2 = 0, bin2 = 0;
+    if (valid2) { read2 = itemRead[item2]; bin2 = itemBin[item2]; }
+    ItemState st2; st2.minErrors = 255; st2.mapped = false; st2.nbuf = 0; st2.defer = false;
+    extendEasyItem<NW, false>(ix, rd, item2, read2, bin2, S0, prm, hits0, sink, hardCount, hardList, false, st2, valid2);
+    flushWaveMatches(st2, read2, sink, lane);
 }
 
 // The re-seeded items listed by k_extend (the list length is only known on the device).
@@ -1029,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_extend_hard(IndexView ix, ReadsView rd,
     EditFrame * editStack = editSlab ? editSlab + (size_t)waveId * editStride : nullptr;
     for (u32 i = waveId; i < n; i += totalWaves)
     {   // one wavefront per re-seeded item (see extendHardItemWave)
-        ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0;
+        ItemState st; st.minErrors = 255; st.mapped = false; st.nbuf = 0; st.defer = false;
         const u32 item = hardList[i];
         const u32 read = itemRead[item];
         extendHardItemWave<NW>(ix, rd, item, read, itemBin[item], S0, prm, hits0, sink, st, lane, editStack);

@@ -53,6 +53,7 @@ void       *dy_ctx_stream(dy_ctx *ctx);
 /* Selects among result-identical code paths / device-only tables of a context (the library never reads the environment).
  * Keys (value range, default): sparse_sa (0-1, 0), prefix_q (0-12, 12), prefix_wide (0-1, 1: 16-byte q-mer table
  * entries that carry the bases following a unique q-mer, when they fit), no_isa (0-1, 0) — read by dy_index_load;
+ * extend_mode (0-2, 1: K3 as a fast pass plus a second launch over the items it could not finish; 0 = each block redoes its own unfinished items; 2 = one full pass);
  * finalize_block_min (>=1, 2048), finalize_no_keys (0-1, 0), pe_heavy_min (>=1, 256), pe_rescue_global (0-1, 0),
  * ibf_narrow (0-1, 0), ibf_full_tail (0-1, 0), ibf_lds_kb (4-60, 12), ibf_dense (0-1, 0), ibf_kernel (0-3, 0: sweep for more than 64 bins chosen from the filter fill; 1 lazy, 2 eager2, 3 wide),
  * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next
@@ -235,7 +236,7 @@ typedef struct {
                                 5 k_ibf_query_eager2, 6 k_ibf_query_wide (0 = none yet) */
     uint32_t ibf_slack;      /* first check of that sweep at nK - threshold + slack k-mers (derived from the sampled filter fill) */
     uint32_t ibf_tail_pre;   /* k_ibf_query_two: tail k-mers requested with the first round (4 where the filter's fill makes weak bins the rule, else 0) */
-    uint32_t reserved;
+    uint32_t second_pass_items;   /* items K3's fast pass could not finish (a side with more than one difference, a third match): redone in full */
 } dy_map_stats;
 int  dy_map_get_stats(const dy_ctx *ctx, dy_map_stats *s);
 
