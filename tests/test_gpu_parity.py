@@ -703,6 +703,63 @@ def test_map_matches_oracle_on_repeats_and_indels(dy, ctx, ob, tmp_path, L, e, s
     if oibf: oibf.close()
 
 
+def _low_complexity_genome(rng, length):
+    """Homopolymer runs, di- and tri-nucleotide repeats between short random stretches: where one substitution and one indel cost the same
+    and an extension's end position ties (the shifted end of extend_sides.h's closed forms)."""
+    parts, total = [], 0
+    while total < length:
+        kind = int(rng.integers(0, 4))
+        if kind == 0: p = np.full(int(rng.integers(3, 30)), rng.integers(0, 4), np.uint8)
+        elif kind == 1: p = np.tile(rng.integers(0, 4, 2, dtype=np.uint8), int(rng.integers(2, 15)))
+        elif kind == 2: p = np.tile(rng.integers(0, 4, 3, dtype=np.uint8), int(rng.integers(2, 10)))
+        else: p = rng.integers(0, 4, int(rng.integers(5, 40)), dtype=np.uint8)
+        parts.append(p); total += p.size
+    return np.concatenate(parts)[:length]
+
+
+@pytest.mark.parametrize("L,e,strata,mode", [(100, 3, 0, 1), (100, 3, 2, 1), (64, 5, 0, 1), (150, 4, 1, 1), (100, 3, 0, 0)])
+def test_extension_closed_forms_on_low_complexity_genomes(dy, ob, tmp_path, L, e, strata, mode):
+    """K3's fast pass closes single-substitution sides without the edit distance search (k_extend<NW, 1>, extend_sides.h); on genomes of
+    homopolymers and short tandem repeats — where the search's end position ties between the diagonal and the shifted end, and substitutions
+    tie with indels — every field still equals the oracle's, and both the fast pass and the second pass have had work."""
+    rng = np.random.default_rng(77 + L + e)
+    n_bins = 4
+    genomes = [_low_complexity_genome(rng, 50000) for _ in range(n_bins)]
+    idx_dir = str(tmp_path / "idx")
+    os.makedirs(idx_dir)
+    for b, g in enumerate(genomes):
+        ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
+    reads = []
+    for i in range(3000):
+        g = genomes[int(rng.integers(0, n_bins))]
+        s = int(rng.integers(0, g.size - L - 3))
+        r = g[s:s + L + 3].copy()
+        for _ in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, L))
+            kind = rng.random()
+            if kind < 0.8: r[p] = (r[p] + 1 + rng.integers(0, 3)) & 3
+            elif kind < 0.9: r = np.concatenate([r[:p], rng.integers(0, 4, 1, dtype=np.uint8), r[p:]])
+            else: r = np.concatenate([r[:p], r[p + 1:]])
+        r = r[:L]
+        if i % 2: r = (3 - r[::-1]).astype(np.uint8)
+        reads.append(r.astype(np.uint8))
+    codes = np.concatenate(reads)
+    offs = np.zeros(len(reads) + 1, np.uint64); offs[1:] = np.cumsum([r.size for r in reads])
+    er, sr = np.float32(e / 100.0), np.float32(strata / 100.0)
+    tctx = dy.Context(0)
+    try:
+        tctx.set_tuning("extend_mode", mode)
+        dev, stats = device_map(dy, tctx, idx_dir, n_bins, None, codes, offs, er, sr, 1)
+    finally:
+        tctx.close()
+    oidx = ob.OracleIndex(idx_dir, n_bins)
+    o_reads, o_matches, o_cigars, ostats = ob.map_batch(oidx, None, codes, offs, er, sr, 1)
+    assert stats["raw_matches"] == ostats["raw_matches"]
+    assert_results_equal(dev, (o_reads, o_matches, o_cigars))
+    assert 0 < stats["second_pass_items"] < stats["items"]
+    oidx.close()
+
+
 def test_pool_overflow_retry_with_reseeded_reads(dy, ob, tmp_path):
     """The raw-match pool starts at 64 records (tuning key pool_cap) while the batch yields ~2 million, most of them from re-seeded
     reads appended 64 at a time by k_extend_hard: every append past the capacity must be dropped and counted, the pool regrown to
