@@ -162,7 +162,7 @@ struct dy_ctx
     DevBuf peHeavy, peItems, peU2, peLib, peLens, peIdx, peHasRescue, peJobs, peScratch, peMCounts, peMStart,
            waveCounts, waveOffsets, complexList, alignList, smallList, binTotals, binStart, binOrderRank, itemRead, itemBin, hits0, pool, counters, readMatchCount, readStart,
            cursor, gp, aux, marr, maux, dp, scanTmp,
-           shLen, shLenOff, shOwner, shTotals, hardList, slowList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
+           shLen, shLenOff, shOdd, shOddOff, shOwner, shTotals, hardList, slowList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
     size_t poolCap = 0;
     DevBuf devItems;                    // u32[4]: [0] the work list's size as the kernels see it, [1] as counted, [2] it did not fit (k_items_clamp)
     double itemsPerRead = 0.0;          // of the last batch mapped: sizes the next batch's work list when nothing waits for its count
@@ -2074,7 +2074,9 @@ static SegTable segTableC1(const dy_seg_header * h, u32 nRanks, u32 W, u64 & nRe
     u64 off = 0; nReads = 0; nBases = 0; maxLen = 0; minLen = 0xFFFFFFFFu;
     for (u32 s = 0; s < nRanks; ++s)
     {
-        if (h[s].bytes != c1SegBytes(h[s].n_reads, h[s].n_bases, W)) throw DyError(DY_EINVAL, "dy_shard_c1_unpack: a segment header does not describe its own size");
+        // bases travel at 4 bits each, every read from a byte of its own: (bases + 1) / 2 .. (bases + reads) / 2 bytes
+        if (h[s].bytes < c1SegBytes(h[s].n_reads, (h[s].n_bases + 1) / 2, W) || h[s].bytes > c1SegBytes(h[s].n_reads, (h[s].n_bases + h[s].n_reads) / 2, W))
+            throw DyError(DY_EINVAL, "dy_shard_c1_unpack: a segment header does not describe its own size");
         T.off[s] = off; T.start[s] = (u32)nReads;
         off += h[s].bytes; nReads += h[s].n_reads; nBases += h[s].n_bases;
         if (nReads > 2097151u) throw DyError(DY_EINVAL, "a batch holds at most 2097151 reads (21-bit read id)");
@@ -2114,7 +2116,7 @@ int dy_shard_c1_pack(dy_ctx * ctx, dy_reads * reads, uint32_t n_ranks, const uin
         hipLaunchKernelGGL(k_c1_count, dim3(std::max(1u, (nWaves + 3) / 4)), dim3(256), 0, st, reads->masks.as<u64>(), reads->offs.as<u64>(), n, W, ctx->shOwner.as<u64>(),
                            n_ranks, nWaves, ctx->shPairs.as<CountPair>());
         {
-            size_t tb = 0; CountPair zero; zero.bases = 0; zero.cnt = 0;
+            size_t tb = 0; CountPair zero; zero.bases = 0; zero.cnt = 0; zero.packed = 0;
             HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(nullptr, tb, ctx->shPairs.as<CountPair>(), ctx->shScan.as<CountPair>(), CountPairSum(), zero, (int)nPairs, st));
             ctx->scanTmp.reserve(tb + 64);
             HIP_CHECK(hipcub::DeviceScan::ExclusiveScan(ctx->scanTmp.p, tb, ctx->shPairs.as<CountPair>(), ctx->shScan.as<CountPair>(), CountPairSum(), zero, (int)nPairs, st));
@@ -2122,7 +2124,7 @@ int dy_shard_c1_pack(dy_ctx * ctx, dy_reads * reads, uint32_t n_ranks, const uin
         const u64 lenRange = (u64)reads->maxLen | ((u64)reads->minLen << 32);
         hipLaunchKernelGGL(k_c1_headers, dim3(1), dim3(MAX_RANKS), 0, st, ctx->shScan.as<CountPair>(), n_ranks, nWaves, W, lenRange, (SegHeader *)headers_dev, ctx->shSegOff.as<u64>());
         // room for the worst case (every read selected by every rank): the sizes are not known on the host, and 288 GB make the bound cheap
-        ctx->shSend.reserve((size_t)n_ranks * (c1SegBytes(n, reads->totalBases, W) + 16) + 64);
+        ctx->shSend.reserve((size_t)n_ranks * (c1SegBytes(n, (reads->totalBases + n) / 2 + 1, W) + 16) + 64);
         if (nWaves)
             hipLaunchKernelGGL(k_c1_pack, dim3((nWaves + 3) / 4), dim3(256), 0, st, reads->masks.as<u64>(), reads->offs.as<u64>(), reads->seqs.as<u8>(), n, W, ctx->shOwner.as<u64>(),
                                n_ranks, nWaves, ctx->shScan.as<CountPair>(), (const SegHeader *)headers_dev, ctx->shSegOff.as<u64>(), ctx->shSend.as<u8>());
@@ -2155,28 +2157,31 @@ int dy_shard_c1_unpack(dy_ctx * ctx, const void * recv_dev, uint32_t n_ranks, co
         takeBuffer(ctx, r->masks, (size_t)n * W * 8 + 8);
         r->maskW = W; r->maskBins = n_bins;
         ctx->shIds.reserve((size_t)n * 4 + 64); ctx->shLen.reserve((size_t)(n + 1) * 8);
+        ctx->shOdd.reserve((size_t)(n + 1) * 4 + 64); ctx->shOddOff.reserve((size_t)(n + 1) * 4 + 64);
         ctx->shFlags.reserve(64);
         HIP_CHECK(hipMemsetAsync(ctx->shFlags.p, 0, 16, st));
         const u8 * recv = (const u8 *)recv_dev;
         const dim3 perRead((n + 1 + 255) / 256), block(256);
         if (!paired)
         {
-            hipLaunchKernelGGL(k_c1_unpack_scalars, perRead, block, 0, st, recv, T, W, n, ctx->shIds.as<u32>(), ctx->shLen.as<u64>(), r->masks.as<u64>(), ctx->shFlags.as<u32>());
+            hipLaunchKernelGGL(k_c1_unpack_scalars, perRead, block, 0, st, recv, T, W, n, ctx->shIds.as<u32>(), ctx->shLen.as<u64>(), ctx->shOdd.as<u32>(), r->masks.as<u64>(), ctx->shFlags.as<u32>());
             exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n + 1);
-            if (n) hipLaunchKernelGGL(k_c1_unpack_bases, dim3(std::min<u32>((n + 15) / 16, 65536u)), block, 0, st, recv, T, W, (const u32 *)nullptr, n, r->offs.as<u64>(), r->offs.as<u64>(),
-                                      nBases, r->seqs.as<u8>(), r->seqsRc.as<u8>(), ctx->shFlags.as<u32>());
+            exclusiveSum(ctx, ctx->shOdd.as<u32>(), ctx->shOddOff.as<u32>(), (size_t)n + 1);
+            if (n) hipLaunchKernelGGL(k_c1_unpack_bases, dim3(std::min<u32>((n + 15) / 16, 65536u)), block, 0, st, recv, T, W, (const u32 *)nullptr, n, r->offs.as<u64>(), ctx->shOddOff.as<u32>(),
+                                      r->offs.as<u64>(), nBases, r->seqs.as<u8>(), r->seqsRc.as<u8>(), ctx->shFlags.as<u32>());
         }
         else
         {
             takeBuffer(ctx, r->orig, (size_t)n * 4 + 64);
             ctx->shFlatLens.reserve((size_t)(n + 1) * 8); ctx->shFlatMasks.reserve((size_t)n * W * 8 + 64); ctx->shLenOff.reserve((size_t)(n + 1) * 8);
             if (n) hipLaunchKernelGGL(k_pair_layout, dim3((n + 255) / 256), block, 0, st, T, n, r->orig.as<u32>());
-            hipLaunchKernelGGL(k_c1_unpack_scalars, perRead, block, 0, st, recv, T, W, n, ctx->shIds.as<u32>(), ctx->shFlatLens.as<u64>(), ctx->shFlatMasks.as<u64>(), ctx->shFlags.as<u32>());
+            hipLaunchKernelGGL(k_c1_unpack_scalars, perRead, block, 0, st, recv, T, W, n, ctx->shIds.as<u32>(), ctx->shFlatLens.as<u64>(), ctx->shOdd.as<u32>(), ctx->shFlatMasks.as<u64>(), ctx->shFlags.as<u32>());
             exclusiveSum(ctx, ctx->shFlatLens.as<u64>(), ctx->shLenOff.as<u64>(), (size_t)n + 1);                // offsets in arrival order
+            exclusiveSum(ctx, ctx->shOdd.as<u32>(), ctx->shOddOff.as<u32>(), (size_t)n + 1);
             hipLaunchKernelGGL(k_permute_scalars, perRead, block, 0, st, r->orig.as<u32>(), n, W, ctx->shFlatLens.as<u64>(), ctx->shFlatMasks.as<u64>(), ctx->shLen.as<u64>(), r->masks.as<u64>());
             exclusiveSum(ctx, ctx->shLen.as<u64>(), r->offs.as<u64>(), (size_t)n + 1);                           // offsets of the re-ordered batch
-            if (n) hipLaunchKernelGGL(k_c1_unpack_bases, dim3(std::min<u32>((n + 15) / 16, 65536u)), block, 0, st, recv, T, W, r->orig.as<u32>(), n, ctx->shLenOff.as<u64>(), r->offs.as<u64>(),
-                                      nBases, r->seqs.as<u8>(), r->seqsRc.as<u8>(), ctx->shFlags.as<u32>());
+            if (n) hipLaunchKernelGGL(k_c1_unpack_bases, dim3(std::min<u32>((n + 15) / 16, 65536u)), block, 0, st, recv, T, W, r->orig.as<u32>(), n, ctx->shLenOff.as<u64>(), ctx->shOddOff.as<u32>(),
+                                      r->offs.as<u64>(), nBases, r->seqs.as<u8>(), r->seqsRc.as<u8>(), ctx->shFlags.as<u32>());
         }
         HIP_CHECK(hipGetLastError());
         // what dy_shard_c2_pack needs of this batch: where each source's reads start in arrival order

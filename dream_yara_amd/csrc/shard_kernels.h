@@ -5,7 +5,7 @@
 // Each exchange is ONE packed buffer per rank, segments destination-major, plus a row of 64-bit counts per destination that the
 // caller exchanges first; nothing here synchronises with the host (sizes stay on the device until the caller fetches the rows).
 //
-//   C1 segment (to owner d):   [ids u32 x n][lens u32 x n][pad to 16][masks u64 x n x W][seqs u8 x bases][pad to 16]
+//   C1 segment (to owner d):   [ids u32 x n][lens u32 x n][pad to 16][masks u64 x n x W][bases, 4 bits each, every read from a byte of its own][pad to 16]
 //   C2 segment (to home s):    [raw matches 16 B x r][pairing records 40 B x i][pad to 16]
 #pragma once
 #include "dy_types.h"
@@ -18,13 +18,15 @@ enum { MAX_RANKS = 64 };
 
 // one row per destination; the ABI's dy_seg_header
 struct SegHeader { u64 a, b, bytes, aux; };            // C1: a = reads, b = bases, aux = maxLen | minLen << 32;  C2: a = raw matches, b = pairing records
-struct CountPair { u64 bases; u64 cnt; };
-struct CountPairSum { __host__ __device__ CountPair operator()(const CountPair & x, const CountPair & y) const { CountPair r; r.bases = x.bases + y.bases; r.cnt = x.cnt + y.cnt; return r; } };
+struct CountPair { u64 bases; u64 cnt; u64 packed; };      // packed = bytes of the reads' bases at 4 bits each
+struct CountPairSum { __host__ __device__ CountPair operator()(const CountPair & x, const CountPair & y) const { CountPair r; r.bases = x.bases + y.bases; r.cnt = x.cnt + y.cnt; r.packed = x.packed + y.packed; return r; } };
+// bytes a read of len bases takes in a C1 segment (Dna5 codes 0..4, two per byte, the first in the low half)
+__host__ __device__ __forceinline__ u32 packedBytesOf(u32 len) { return (len + 1) >> 1; }
 
 __host__ __device__ __forceinline__ u64 roundUp16(u64 x) { return (x + 15) & ~(u64)15; }
 __host__ __device__ __forceinline__ u64 c1ScalarBytes(u64 n) { return roundUp16(8 * n); }                       // ids + lens
 __host__ __device__ __forceinline__ u64 c1SeqOffset(u64 n, u32 W) { return c1ScalarBytes(n) + 8 * n * W; }      // masks follow the scalars (16-aligned), bases follow the masks
-__host__ __device__ __forceinline__ u64 c1SegBytes(u64 n, u64 bases, u32 W) { return roundUp16(c1SeqOffset(n, W) + bases); }
+__host__ __device__ __forceinline__ u64 c1SegBytes(u64 n, u64 packed, u32 W) { return roundUp16(c1SeqOffset(n, W) + packed); }
 __host__ __device__ __forceinline__ u64 c2SegBytes(u64 raws, u64 items) { return roundUp16(16 * raws + 40 * items); }
 
 // bit d of the result: read i has a selected bin among those rank d owns
@@ -54,13 +56,58 @@ __device__ __forceinline__ u32 waveExclusiveSumU32(u32 v)
     return x - v;
 }
 
+// 8 Dna5 codes (one per byte) <-> 32 bits, code j in bits 4j..4j+3
+__device__ __forceinline__ u32 packNibbles8(u64 w)
+{
+    w &= 0x0F0F0F0F0F0F0F0Full;
+    w = (w | (w >> 4)) & 0x00FF00FF00FF00FFull;
+    w = (w | (w >> 8)) & 0x0000FFFF0000FFFFull;
+    return (u32)(w | (w >> 16));
+}
+__device__ __forceinline__ u64 unpackNibbles8(u32 p)
+{
+    u64 w = p;
+    w = (w | (w << 16)) & 0x0000FFFF0000FFFFull;
+    w = (w | (w << 8)) & 0x00FF00FF00FF00FFull;
+    return (w | (w << 4)) & 0x0F0F0F0F0F0F0F0Full;
+}
+struct __attribute__((packed)) PackedU32sh { u32 v; };
+// g = lane of a group of 16.  src[0, len) at one code per byte -> dst[0, packedBytesOf(len)) at two per byte
+__device__ __forceinline__ void groupPackRead(const u8 * __restrict__ src, u8 * __restrict__ dst, u32 len, u32 g)
+{
+    for (u32 p = g * 8; p + 8 <= len; p += 128) ((PackedU32sh *)(dst + (p >> 1)))->v = packNibbles8(((const PackedU64rc *)(src + p))->v);
+    const u32 t = len & ~7u, rest = len - t;              // < 8 codes -> up to 4 bytes, one per lane
+    if (2 * g < rest)
+    {
+        const u32 lo = src[t + 2 * g], hi = 2 * g + 1 < rest ? src[t + 2 * g + 1] : 0u;
+        dst[(t >> 1) + g] = (u8)((lo & 15u) | (hi << 4));
+    }
+}
+// ... and back, with the reverse complement (rc may be NULL)
+__device__ __forceinline__ void groupUnpackRead(const u8 * __restrict__ src, u8 * __restrict__ dst, u8 * __restrict__ rc, u32 len, u32 g)
+{
+    for (u32 p = g * 8; p + 8 <= len; p += 128)
+    {
+        const u64 w = unpackNibbles8(((const PackedU32sh *)(src + (p >> 1)))->v);
+        ((PackedU64rc *)(dst + p))->v = w;
+        if (rc) ((PackedU64rc *)(rc + len - 8 - p))->v = revcomp8(w);
+    }
+    const u32 t = len & ~7u;
+    if (g < (len & 7u))
+    {
+        const u8 c = (u8)((src[(t + g) >> 1] >> (4 * ((t + g) & 1u))) & 15u);
+        dst[t + g] = c;
+        if (rc) rc[len - 1 - (t + g)] = c < 4 ? (u8)(3 - c) : c;
+    }
+}
+
 // ---- C1, home side --------------------------------------------------------------------------------------------------------------
 // One wavefront per 64 reads: pairs[d * nWaves + wave] = (reads, bases) of the wavefront that go to rank d; entry nRanks * nWaves = 0.
 __global__ __launch_bounds__(256) void k_c1_count(const u64 * __restrict__ masks, const u64 * __restrict__ offs, u32 n, u32 W, const u64 * __restrict__ owner,
                                                   u32 nRanks, u32 nWaves, CountPair * __restrict__ pairs)
 {
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wave == 0 && lane == 0) { CountPair z; z.bases = 0; z.cnt = 0; pairs[(size_t)nRanks * nWaves] = z; }
+    if (wave == 0 && lane == 0) { CountPair z; z.bases = 0; z.cnt = 0; z.packed = 0; pairs[(size_t)nRanks * nWaves] = z; }
     if (wave >= nWaves) return;
     const u32 i = wave * 64 + lane;
     const bool valid = i < n;
@@ -71,7 +118,8 @@ __global__ __launch_bounds__(256) void k_c1_count(const u64 * __restrict__ masks
         const bool mine = (sel >> d) & 1;
         const u64 b = __ballot(mine);
         const u32 bases = b ? waveSumU32(mine ? len : 0) : 0;
-        if (lane == 0) { CountPair p; p.bases = bases; p.cnt = (u64)__popcll(b); pairs[(size_t)d * nWaves + wave] = p; }
+        const u32 packed = b ? waveSumU32(mine ? packedBytesOf(len) : 0) : 0;
+        if (lane == 0) { CountPair p; p.bases = bases; p.cnt = (u64)__popcll(b); p.packed = packed; pairs[(size_t)d * nWaves + wave] = p; }
     }
 }
 
@@ -83,7 +131,7 @@ __global__ void k_c1_headers(const CountPair * __restrict__ scan, u32 nRanks, u3
     if (d < nRanks)
     {
         const CountPair lo = scan[(size_t)d * nWaves], hi = scan[(size_t)(d + 1) * nWaves];
-        SegHeader h; h.a = hi.cnt - lo.cnt; h.b = hi.bases - lo.bases; h.bytes = c1SegBytes(h.a, h.b, W); h.aux = lenRange;
+        SegHeader h; h.a = hi.cnt - lo.cnt; h.b = hi.bases - lo.bases; h.bytes = c1SegBytes(h.a, hi.packed - lo.packed, W); h.aux = lenRange;
         headers[d] = h; bytes[d] = h.bytes;
     }
     __syncthreads();
@@ -111,7 +159,7 @@ __global__ __launch_bounds__(256) void k_c1_pack(const u64 * __restrict__ masks,
         const u64 nSeg = headers[d].a;
         u8 * seg = out + segOff[d];
         const u32 pos = (u32)(at.cnt - start.cnt) + (u32)__popcll(b & ((1ull << lane) - 1));
-        const u64 dst = c1SeqOffset(nSeg, W) + (at.bases - start.bases) + waveExclusiveSumU32(mine ? len : 0);
+        const u64 dst = c1SeqOffset(nSeg, W) + (at.packed - start.packed) + waveExclusiveSumU32(mine ? packedBytesOf(len) : 0);
         if (mine)
         {
             ((u32 *)seg)[pos] = i; ((u32 *)seg)[nSeg + pos] = len;
@@ -128,7 +176,7 @@ __global__ __launch_bounds__(256) void k_c1_pack(const u64 * __restrict__ masks,
             const int from = mine4 < 0 ? (int)lane : mine4;
             const u64 s = __shfl(src, from, 64), dd = __shfl(dst, from, 64);
             const u32 L = __shfl(len, from, 64);
-            if (mine4 >= 0) groupCopyRead(seqs + s, seg + dd, nullptr, L, lane & 15);
+            if (mine4 >= 0) groupPackRead(seqs + s, seg + dd, L, lane & 15);
         }
     }
 }
@@ -150,27 +198,30 @@ __device__ __forceinline__ u32 segmentOf(const u32 * __restrict__ segStarts, u32
 }
 
 // arrival order: home id, widened length (n + 1 entries, the last one 0) and bin masks of every received read
-__global__ void k_c1_unpack_scalars(const u8 * __restrict__ recv, SegTable T, u32 W, u32 n, u32 * __restrict__ ids, u64 * __restrict__ lensWide, u64 * __restrict__ masksOut,
-                                    u32 * __restrict__ bad)
+// (+ oddLens: 1 where the length is odd — a read's bytes in the segment are (bases + odd reads before it) / 2 from the segment's first)
+__global__ void k_c1_unpack_scalars(const u8 * __restrict__ recv, SegTable T, u32 W, u32 n, u32 * __restrict__ ids, u64 * __restrict__ lensWide, u32 * __restrict__ oddLens,
+                                    u64 * __restrict__ masksOut, u32 * __restrict__ bad)
 {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > n) return;
-    if (j == n) { lensWide[j] = 0; return; }
+    if (j == n) { lensWide[j] = 0; oddLens[j] = 0; return; }
     const u32 s = segmentOf(T.start, T.nRanks, j), local = j - T.start[s], nSeg = T.start[s + 1] - T.start[s];
     const u8 * seg = recv + T.off[s];
     u32 len = ((const u32 *)seg)[nSeg + local];
     if (len > 8191) { len = 0; atomicExch(bad, 1u); }          // reference src/mapper.h:453-454; a record the sender could not have packed
     ids[j] = ((const u32 *)seg)[local];
     lensWide[j] = len;
+    oddLens[j] = len & 1u;
     const u64 * mi = (const u64 *)(seg + c1ScalarBytes(nSeg)) + (size_t)local * W;
     for (u32 w = 0; w < W; ++w) masksOut[(size_t)j * W + w] = mi[w];
 }
 
 // bases of the owner-side batch and their reverse complements (appendReverseComplement, reference src/store_seqs.h:271-290), 16 lanes per
 // read.  orig (may be NULL): arrival index of read j (paired batches are re-ordered); arrOffs = exclusive scan of the lengths in
-// arrival order, offsOut = offsets of the batch.
+// arrival order, arrOdd = exclusive scan of the odd-length flags in arrival order, offsOut = offsets of the batch.
 __global__ __launch_bounds__(256) void k_c1_unpack_bases(const u8 * __restrict__ recv, SegTable T, u32 W, const u32 * __restrict__ orig, u32 n, const u64 * __restrict__ arrOffs,
-                                                         const u64 * __restrict__ offsOut, u64 totalBases, u8 * __restrict__ seqsOut, u8 * __restrict__ rcOut, u32 * __restrict__ bad)
+                                                         const u32 * __restrict__ arrOdd, const u64 * __restrict__ offsOut, u64 totalBases, u8 * __restrict__ seqsOut,
+                                                         u8 * __restrict__ rcOut, u32 * __restrict__ bad)
 {
     const u32 g = threadIdx.x & 15;
     const u32 group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, nGroups = (gridDim.x * blockDim.x) >> 4;
@@ -178,11 +229,11 @@ __global__ __launch_bounds__(256) void k_c1_unpack_bases(const u8 * __restrict__
     {
         const u32 a = orig ? orig[j] : j;
         const u32 s = segmentOf(T.start, T.nRanks, a), nSeg = T.start[s + 1] - T.start[s];
-        const u64 src = T.off[s] + c1SeqOffset(nSeg, W) + (arrOffs[a] - arrOffs[T.start[s]]);
+        const u64 src = T.off[s] + c1SeqOffset(nSeg, W) + ((arrOffs[a] - arrOffs[T.start[s]]) + (arrOdd[a] - arrOdd[T.start[s]])) / 2;
         const u64 dst = offsOut[j];
         const u32 len = (u32)(offsOut[j + 1] - dst);
         if (dst + len > totalBases) { if (g == 0) atomicExch(bad, 1u); continue; }      // the lengths do not add up to the bases announced
-        groupCopyRead(recv + src, seqsOut + dst, rcOut + dst, len, g);
+        groupUnpackRead(recv + src, seqsOut + dst, rcOut + dst, len, g);
     }
 }
 

@@ -295,7 +295,8 @@ typedef struct { uint64_t n_reads, n_bases, bytes, aux; } dy_seg_header;
  * travel wherever either is selected.  Queues the packing on the context's stream and returns at once:
  *   headers_dev (DEVICE, caller-owned, n_ranks x dy_seg_header): row d describes the segment for rank d;
  *   *send_dev: the context's packed buffer, segments for ranks 0..n_ranks-1 back to back — per segment the read ids on this rank
- *   (u32), lengths (u32), masks restricted to the destination's bins (W words per read), forward Dna5 codes; valid until the next call. */
+ *   (u32), lengths (u32), masks restricted to the destination's bins (W words per read), forward Dna5 codes at 4 bits each (two per byte, the first in the
+ *   low half; every read starts a byte of its own); valid until the next call.  The layout is the library's own on both ends. */
 int  dy_shard_c1_pack(dy_ctx *ctx, dy_reads *reads, uint32_t n_ranks, const uint64_t *owner_masks, uint32_t paired, void *headers_dev, void **send_dev);
 /* The owner-side batch from the segments received from ranks 0..n_ranks-1 (recv_dev: DEVICE, back to back; recv_headers: HOST, the rows
  * the sources sent for this rank).  A paired batch is re-ordered to [all first mates | all second mates], pairs in source order,

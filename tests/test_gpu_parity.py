@@ -437,7 +437,8 @@ def test_owner_side_batch_ignores_mask_bits_beyond_the_bins(dy, ob, small_filter
         def run(m):
             lens = np.diff(offs).astype(np.uint32)
             body = np.arange(n, dtype=np.uint32).tobytes() + lens.tobytes()
-            body += b"\0" * (-len(body) % 16) + m.astype("<u8").tobytes() + codes.tobytes()
+            packed = (codes[0::2] | (codes[1::2] << 4)).astype(np.uint8)       # 100-base reads: two codes per byte, the first in the low half
+            body += b"\0" * (-len(body) % 16) + m.astype("<u8").tobytes() + packed.tobytes()
             body += b"\0" * (-len(body) % 16)
             hdr = np.zeros(1, dy.SEG_HEADER_DTYPE)
             hdr["n_reads"], hdr["n_bases"], hdr["bytes"], hdr["aux"] = n, codes.size, len(body), 100 | (100 << 32)
@@ -1531,10 +1532,11 @@ def _run_sharded_workers(tmp_path, n_bins, k, strata, port, extra=()):
     return outs
 
 
-@pytest.mark.parametrize("strata,n_bins", [(0.0, 6), (0.02, 6), (0.0, 70)])
-def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata, n_bins):
+@pytest.mark.parametrize("strata,n_bins,ragged", [(0.0, 6, False), (0.02, 6, False), (0.0, 70, False), (0.0, 6, True)])
+def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata, n_bins, ragged):
     """two ranks (both on cuda:0, exchanges over gloo) each hold the FM structures of half the bins; the
-    merged per-read results equal the single-GPU run on the concatenated batch (which the other tests tie to the oracle)."""
+    merged per-read results equal the single-GPU run on the concatenated batch (which the other tests tie to the oracle).
+    ragged: reads of 61..100 bases, odd lengths among them (the bases travel two per byte, every read from a byte of its own)."""
     rng = np.random.default_rng(99)
     k = 16
     genomes, fam = _repeat_genomes(rng, n_bins, 60000 if n_bins < 10 else 8000)      # 70 bins: two mask words per read
@@ -1544,6 +1546,11 @@ def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, str
     goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
     ob.build_filter(str(tmp_path / "f.filter"), n_bins, 3, k, 1 << 24, np.concatenate(genomes), goffs)
     codes, offs = _sample_reads(rng, genomes, fam, 2998, 100, 3)
+    if ragged:
+        keep = rng.integers(61, 101, offs.size - 1)
+        codes = np.concatenate([codes[int(offs[i]):int(offs[i]) + int(keep[i])] for i in range(offs.size - 1)])
+        offs = np.zeros(keep.size + 1, np.uint64); offs[1:] = np.cumsum(keep)
+        assert (keep & 1).sum() > 500
     np.savez(str(tmp_path / "reads.npz"), codes=codes, offs=offs)
     outs = _run_sharded_workers(tmp_path, n_bins, k, strata, 29617)
     assert sum(o["n"] for o in outs) == 3000 and sum(o["mapped"] for o in outs) > 2000
