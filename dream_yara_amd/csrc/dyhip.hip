@@ -2259,7 +2259,8 @@ int dy_shard_c2_pack(dy_ctx * ctx, void * rows_dev, void ** send_dev)
         HIP_CHECK(hipMemsetAsync(counts, 0, 2 * MAX_RANKS * 4, st));
         const u32 * orig = paired ? ctx->shOrig.as<u32>() : nullptr;
         const u32 * nPoolDev = ctx->counters.as<u32>() + COUNTER_POOL64, * nItemsDev = ctx->devItemCount;
-        const u32 rawBlocks = std::min<u32>((n + 255) / 256, 2048u), itemBlocks = std::min<u32>((nItems + 255) / 256, 2048u);
+        const u32 rawBlocks = std::min<u32>((n + 255) / 256, 512u), itemBlocks        // (every block ends in same-address atomics: few, fat blocks)
+                   = std::min<u32>((nItems + 255) / 256, 2048u);
         if (n) hipLaunchKernelGGL(k_raw_seg_count, dim3(rawBlocks), dim3(256), 0, st, ctx->pool.as<RawMatch>(), nPoolDev, T, orig, counts);
         if (paired && nItems)
             hipLaunchKernelGGL(k_pe_items_seg_count, dim3(itemBlocks), dim3(256), 0, st, ctx->peItems.as<PeItem>(), ctx->itemRead.as<u32>(), nItemsDev, T, orig, itemCounts);
