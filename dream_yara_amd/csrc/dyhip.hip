@@ -1,6 +1,7 @@
 // libdyhip.so — C ABI (include/dyhip.h) over the gfx950 kernels. Host code is plumbing only: file parsing, HBM
 // allocation, kernel launches on one HIP stream, result mirroring. No compute falls back to the host.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <cstring>
@@ -116,6 +117,7 @@ struct Tuning
 {
     u64 sparseSa = 0;           // 1 = keep the on-disk SA sampling (no expanded SA)
     u64 prefixQ = 12;           // q of the q-mer range table (0 = none); capped by the free HBM at load
+    u64 markers = 0;            // 1 = roctx ranges around the stages (dy:sweep, dy:items, dy:search, dy:extend, dy:finalize) for rocprofv3 --marker-trace
     u64 extendMode = 1;         // K3: 1 fast pass + a second launch over the listed rest (k_extend MODE 1 + 0), 0 fast pass + the block's own rest in full (MODE 2), 2 one full pass (MODE 0)
     u64 prefixWide = 1;         // 16-byte table entries that carry the bases after a unique q-mer (k_prefix_wide), when they fit
     u64 noIsa = 0;              // 1 = no inverse SA / indexed text (pure LF walk)
@@ -144,6 +146,44 @@ struct dy_ibf; struct dy_reads;
 // dy_ibf_query_deferred: the sweep of the batch mapped next, launched chunk by chunk in front of the host's waits
 struct PendingSweep { dy_ibf * f = nullptr; dy_reads * reads = nullptr; u32 threshold = 0, next = 0, slot = 0; };
 struct SweepTiming { enum { MAX_CHUNKS = 24 }; hipEvent_t ev[2 * MAX_CHUNKS] = {}; u32 nChunks = 0; bool complete = false; };
+
+// Stage ranges for a profiler (reference: the Stats timers of src/mapper.h:238-279 are the only observability it has).
+// roctx is bound at run time and only when the tuning key `markers` asks for it: the library links no profiler.
+struct Markers
+{
+    void * lib = nullptr;
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+    void load()
+    {
+        if (tried) return;
+        tried = true;
+        for (const char * name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+        {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) return;
+        push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+        pop = (int (*)())dlsym(lib, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+static Markers g_markers;
+static void markBegin(bool enabled, const char * name) { if (!enabled) return; g_markers.load(); if (g_markers.push) g_markers.push(name); }
+static void markEnd(bool enabled) { if (enabled && g_markers.pop) g_markers.pop(); }
+struct StageRange
+{
+    bool on;
+    StageRange(bool enabled, const char * name) : on(false)
+    {
+        if (!enabled) return;
+        g_markers.load();
+        if (g_markers.push) { g_markers.push(name); on = true; }
+    }
+    ~StageRange() { if (on) g_markers.pop(); }
+};
 
 struct dy_ctx
 {
@@ -556,10 +596,14 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         HIP_CHECK(hipEventRecord(ctx->ev[2], st));
         u32 asyncCap = 0;
         if (async) asyncCap = (u32)std::min<double>(2.0e9, (double)nReads * ctx->itemsPerRead * 1.25 + 4096.0);
-        const u32 nItems = buildWorkList(ctx, reads, nBins, asyncCap);
+        u32 nItemsBuilt = 0;
+        { StageRange range(ctx->tune.markers != 0, "dy:items"); nItemsBuilt = buildWorkList(ctx, reads, nBins, asyncCap); }
+        const u32 nItems = nItemsBuilt;
         const u32 * nItemsDev = ctx->devItemCount;
         ctx->stats.items = async ? 0 : nItems;
         HIP_CHECK(hipEventRecord(ctx->ev[3], st));
+        const bool marks = ctx->tune.markers != 0;
+        markBegin(marks, "dy:search");
 
         // ---- K2: exact search of the round-0 seeds
         const IndexView ix = idx->view();
@@ -591,6 +635,8 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
             }
         }
         HIP_CHECK(hipEventRecord(ctx->ev[4], st));
+        markEnd(marks);
+        StageRange extendRange(marks, "dy:extend");
 
         // ---- K3: classify, rank, locate, extend -> raw match pool (grown and re-run on overflow)
         ctx->counters.reserve(COUNTER_BYTES);
@@ -654,6 +700,7 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
                         u32 nItems, u32 maxMatchErr, u32 peStages = PE_OWNER | PE_HOME, const u32 * nPoolDev = nullptr /* the real count, where nPool is only its bound */)
 {
         hipStream_t st = ctx->stream;
+        StageRange finalizeRange(ctx->tune.markers != 0, "dy:finalize");
         const u32 nReads = reads->n, nBins = (u32)idx->bins.size(), W = (nBins + 63) / 64;
         const bool paired = p->paired != 0;
         const IndexView ix = idx->view();
@@ -938,7 +985,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
         if (!ctx || !key) throw DyError(DY_EINVAL, "dy_ctx_set_tuning: NULL argument");
         Tuning & t = ctx->tune;
         const struct { const char * name; u64 * slot; u64 lo, hi; } keys[] = {
-            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"extend_mode", &t.extendMode, 0, 2}, {"no_isa", &t.noIsa, 0, 1},
+            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"extend_mode", &t.extendMode, 0, 2}, {"markers", &t.markers, 0, 1}, {"no_isa", &t.noIsa, 0, 1},
             {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},
@@ -1242,6 +1289,7 @@ void dy_reads_free(dy_reads * r)
 static void launchSweep(dy_ibf * f, dy_reads * reads, u32 threshold, u32 first, u32 count, hipStream_t sq)
 {
             dy_ctx * ctx = f->ctx;
+            StageRange sweepRange(ctx->tune.markers != 0, "dy:sweep");
             const u32 W = f->g.W;
             const u64 * offs = reads->offs.as<u64>() + first;
             u64 * masks = reads->masks.as<u64>() + (size_t)first * W;
