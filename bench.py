@@ -546,6 +546,8 @@ def main():
     ap.add_argument("--extras-budget", type=float, default=420.0, help="seconds of wall clock after which no further extra measurement is started")
     ap.add_argument("--e2e-reads", type=int, default=32_000_000)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="dy_ctx_set_tuning knob for experiments (result-identical code paths; see include/dyhip.h)")
+    ap.add_argument("--rehearse", action="store_true", help="N > 1 on a box with fewer GPUs than ranks: ranks share the devices (rank mod devices) and "
+                    "talk over gloo — checks the multi-rank code path, its numbers mean nothing")
     ap.add_argument("--work-dir", default=os.environ.get("DY_BENCH_DIR", "/tmp/dy_bench_%d" % os.getuid()))
     args = ap.parse_args()
     capture_stdout()
@@ -564,7 +566,9 @@ def main():
     # torch (which brings its own HIP runtime) comes up before libdyhip touches the device: the other order leaves torch without a GPU
     import torch
     need_dist = world > 1 or "bins" in legs or extras
-    grp = Group("nccl" if need_dist else None, force=need_dist)
+    grp = Group(("gloo" if args.rehearse else "nccl") if need_dist else None, force=need_dist)
+    if args.rehearse:
+        grp.local_rank %= max(1, torch.cuda.device_count())
     rank = grp.rank
     import dream_yara_amd as dy
     from dream_yara_amd import build as dybuild
