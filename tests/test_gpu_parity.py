@@ -1536,7 +1536,7 @@ def _run_sharded_workers(tmp_path, n_bins, k, strata, port, extra=()):
 def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, strata, n_bins, ragged):
     """two ranks (both on cuda:0, exchanges over gloo) each hold the FM structures of half the bins; the
     merged per-read results equal the single-GPU run on the concatenated batch (which the other tests tie to the oracle).
-    ragged: reads of 61..100 bases, odd lengths among them (the bases travel two per byte, every read from a byte of its own)."""
+    ragged: reads of 61..200 bases, odd lengths among them (the bases travel two per byte, every read from a byte of its own)."""
     rng = np.random.default_rng(99)
     k = 16
     genomes, fam = _repeat_genomes(rng, n_bins, 60000 if n_bins < 10 else 8000)      # 70 bins: two mask words per read
@@ -1545,9 +1545,9 @@ def test_bin_sharded_two_ranks_equal_single_gpu(product_build, ob, tmp_path, str
         ob.build_bin_index(os.path.join(idx_dir, str(b)), g, np.array([0, g.size], np.uint64))
     goffs = np.zeros(n_bins + 1, np.uint64); goffs[1:] = np.cumsum([g.size for g in genomes])
     ob.build_filter(str(tmp_path / "f.filter"), n_bins, 3, k, 1 << 24, np.concatenate(genomes), goffs)
-    codes, offs = _sample_reads(rng, genomes, fam, 2998, 100, 3)
+    codes, offs = _sample_reads(rng, genomes, fam, 2998, 200 if ragged else 100, 3)
     if ragged:
-        keep = rng.integers(61, 101, offs.size - 1)
+        keep = rng.integers(61, 201, offs.size - 1)
         codes = np.concatenate([codes[int(offs[i]):int(offs[i]) + int(keep[i])] for i in range(offs.size - 1)])
         offs = np.zeros(keep.size + 1, np.uint64); offs[1:] = np.cumsum(keep)
         assert (keep & 1).sum() > 500
