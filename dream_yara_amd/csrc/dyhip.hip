@@ -118,7 +118,8 @@ struct Tuning
     u64 sparseSa = 0;           // 1 = keep the on-disk SA sampling (no expanded SA)
     u64 prefixQ = 12;           // q of the q-mer range table (0 = none); capped by the free HBM at load
     u64 markers = 0;            // 1 = roctx ranges around the stages (dy:sweep, dy:items, dy:search, dy:extend, dy:finalize) for rocprofv3 --marker-trace
-    u64 extendMode = 1;         // K3: 1 fast pass + a second launch over the listed rest (k_extend MODE 1 + 0), 0 fast pass + the block's own rest in full (MODE 2), 2 one full pass (MODE 0)
+    u64 extendMode = 3;         // K3: 3 = 1 or 2 by the share of items the last fast pass could not finish (see launchExtend); 1 fast pass + a second launch
+                                // over the listed rest (k_extend MODE 1 + 0), 0 fast pass + the block's own rest in full (MODE 2), 2 one full pass (MODE 0)
     u64 prefixWide = 1;         // 16-byte table entries that carry the bases after a unique q-mer (k_prefix_wide), when they fit
     u64 noIsa = 0;              // 1 = no inverse SA / indexed text (pure LF walk)
     u64 finalizeBlockMin = 2048;// reads with more raw matches are aggregated by a 1024-thread block
@@ -205,6 +206,8 @@ struct dy_ctx
            shLen, shLenOff, shOdd, shOddOff, shOwner, shTotals, hardList, slowList, dpList, itemKeys, itemPerm, orderHist, orderCursor, editSlab;
     size_t poolCap = 0;
     DevBuf devItems;                    // u32[4]: [0] the work list's size as the kernels see it, [1] as counted, [2] it did not fit (k_items_clamp)
+    double extendLeftShare = 0.0;       // items the last two-launch K3 left to its second pass / items (extend_mode 3)
+    u32 extendOnePassBatches = 0, extendModeUsed = 1;
     double itemsPerRead = 0.0;          // of the last batch mapped: sizes the next batch's work list when nothing waits for its count
     PinnedBuf hostUp;                   // staging of dy_reads_upload
     PinnedBuf hostCounters, hostItems;
@@ -419,7 +422,15 @@ static void launchExtend(dy_ctx * ctx, const IndexView & ix, const ReadsView & r
 {
     const dim3 grid(((nItems + 255) / 256 + 7) / 8 * 8);
     u32 * counters = ctx->counters.as<u32>();
-    const u32 mode = mp.sensitivity == 2 ? 2u : (u32)ctx->tune.extendMode;          // -y full: edit-distance seeds, no fast pass (tuning extend_mode)
+    u32 mode = mp.sensitivity == 2 ? 2u : (u32)ctx->tune.extendMode;          // -y full: edit-distance seeds, no fast pass (tuning extend_mode)
+    if (mode == 3)
+    {   // The fast pass pays when few items need the second one (10 % at the default error profile: even; 19 % at 150 bp / 5 %: 1.38 -> 1.13 ms)
+        // and costs when most do (reads with 1-3 % substitutions: 1.08 against 0.85 ms per 1 M reads).  The share the last fast pass left over
+        // decides for the batches that follow; after 15 one-pass batches a two-launch batch measures it again.
+        mode = 1;
+        if (ctx->extendLeftShare > 0.30 && ctx->extendOnePassBatches > 0) mode = 2;
+    }
+    ctx->extendModeUsed = mode;
     if (mode == 0)          // fast pass, then each block redoes what it left (counters[0]: how many items that was)
         hipLaunchKernelGGL((k_extend<NW, 2>), grid, dim3(256), 0, ctx->stream, ix, rv, ctx->itemRead.as<u32>(), ctx->itemBin.as<u16>(),
                            ctx->devItemCount, S0, mp, ctx->hits0.as<uint2>(), sink, counters + 2, ctx->hardList.as<u32>(), ctx->itemPerm.as<u32>(), counters, (u32 *)nullptr, 1u);
@@ -685,6 +696,12 @@ static void runSearchExtend(dy_ctx * ctx, const dy_index * idx, dy_reads * reads
         if (!async)
         {
             ctx->stats.raw_matches = nPool; ctx->stats.hard_items = hostCounters[2] - hostCounters[12]; ctx->stats.second_pass_items = hostCounters[0];     // re-seeded items, as the reference counts them
+            if (ctx->extendModeUsed == 1 && nItems)
+            {
+                ctx->extendLeftShare = (double)hostCounters[0] / (double)nItems;
+                ctx->extendOnePassBatches = ctx->extendLeftShare > 0.30 ? 15u : 0u;
+            }
+            else if (ctx->extendModeUsed == 2 && ctx->extendOnePassBatches) --ctx->extendOnePassBatches;
             if (nReads) ctx->itemsPerRead = std::max(0.25, (double)nItems / (double)nReads);
         }
         nItemsOut = nItems; nPoolOut = nPool;
@@ -985,7 +1002,7 @@ int dy_ctx_set_tuning(dy_ctx * ctx, const char * key, uint64_t value)
         if (!ctx || !key) throw DyError(DY_EINVAL, "dy_ctx_set_tuning: NULL argument");
         Tuning & t = ctx->tune;
         const struct { const char * name; u64 * slot; u64 lo, hi; } keys[] = {
-            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"extend_mode", &t.extendMode, 0, 2}, {"markers", &t.markers, 0, 1}, {"no_isa", &t.noIsa, 0, 1},
+            {"sparse_sa", &t.sparseSa, 0, 1}, {"prefix_q", &t.prefixQ, 0, 12}, {"prefix_wide", &t.prefixWide, 0, 1}, {"extend_mode", &t.extendMode, 0, 3}, {"markers", &t.markers, 0, 1}, {"no_isa", &t.noIsa, 0, 1},
             {"finalize_block_min", &t.finalizeBlockMin, 1, 0xFFFFFFF0ull}, {"finalize_no_keys", &t.finalizeNoKeys, 0, 1},
             {"pe_heavy_min", &t.peHeavyMin, 1, 0xFFFFFFF0ull}, {"pe_rescue_global", &t.peRescueGlobal, 0, 1},
             {"ibf_narrow", &t.ibfNarrow, 0, 1}, {"ibf_full_tail", &t.ibfFullTail, 0, 1}, {"ibf_lds_kb", &t.ibfLdsKb, 4, 60}, {"ibf_dense", &t.ibfDense, 0, 1},

@@ -55,7 +55,8 @@ void       *dy_ctx_stream(dy_ctx *ctx);
  * entries that carry the bases following a unique q-mer, when they fit), no_isa (0-1, 0) — read by dy_index_load;
  * markers (0-1, 0: 1 = roctx ranges dy:sweep / dy:items / dy:search / dy:extend / dy:finalize around the stages' launches, for
  * rocprofv3 --marker-trace; the roctx library is bound at run time, only then),
- * extend_mode (0-2, 1: K3 as a fast pass plus a second launch over the items it could not finish; 0 = each block redoes its own unfinished items; 2 = one full pass);
+ * extend_mode (0-3, 3: 1 or 2, chosen per batch from the share of items the last fast pass left over; 1 = K3 as a fast pass plus a second
+ * launch over the items it could not finish; 0 = each block redoes its own unfinished items; 2 = one full pass);
  * finalize_block_min (>=1, 2048), finalize_no_keys (0-1, 0), pe_heavy_min (>=1, 256), pe_rescue_global (0-1, 0),
  * ibf_narrow (0-1, 0), ibf_full_tail (0-1, 0), ibf_lds_kb (4-60, 12), ibf_dense (0-1, 0), ibf_kernel (0-3, 0: sweep for more than 64 bins chosen from the filter fill; 1 lazy, 2 eager2, 3 wide),
  * ibf_slack (0-255, 0 = from the fill), ibf_own_stream (0-1, 0: 1 = dy_ibf_query runs on a second stream of the context, so the next

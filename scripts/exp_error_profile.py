@@ -31,5 +31,6 @@ for name, kw in (("error-free", dict(sub_lo=0.0, sub_hi=0.0, indel_rate=0.0)), (
             for k in ("ms_ibf", "ms_items", "ms_search", "ms_extend", "ms_finalize"):
                 acc[k] = acc.get(k, 0) + st[k] / 5
         res.close()
-    print("%-20s %s raw/read %.3f" % (name, {k: round(v, 3) for k, v in acc.items()}, st["raw_matches"] / wl["reads"]), flush=True)
+    print("%-20s %s raw/read %.3f second-pass items/read %.3f (last batch)" % (name, {k: round(v, 3) for k, v in acc.items()}, st["raw_matches"] / wl["reads"],
+                                                                                   st["second_pass_items"] / wl["reads"]), flush=True)
     reads.close()

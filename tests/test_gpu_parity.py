@@ -551,7 +551,7 @@ def test_deferred_sweep_gives_the_same_masks_and_results(dy, ob, small_filter, c
 
 
 @pytest.mark.parametrize("tuning", [{"sparse_sa": 1}, {"prefix_q": 0}, {"no_isa": 1}, {"prefix_q": 6}, {"finalize_block_min": 3, "finalize_no_keys": 1},
-                                    {"ibf_full_tail": 1}, {"items_sorted": 0}, {"async_map": 1}, {"prefix_wide": 0}, {"prefix_q": 6, "prefix_wide": 0}, {"extend_mode": 0}, {"extend_mode": 2}, {"markers": 1}])
+                                    {"ibf_full_tail": 1}, {"items_sorted": 0}, {"async_map": 1}, {"prefix_wide": 0}, {"prefix_q": 6, "prefix_wide": 0}, {"extend_mode": 0}, {"extend_mode": 1}, {"extend_mode": 2}, {"markers": 1}])
 def test_map_without_the_device_only_tables(dy, ob, small_filter, tuning):
     """The HBM-sized tables (expanded SA, q-mer ranges, inverse SA + indexed text) only accelerate: with each of them switched
     off at load time (dy_ctx_set_tuning) the results stay identical to the oracle (sparse-SA walk, plain LF search, row-range
