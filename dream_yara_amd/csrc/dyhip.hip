@@ -787,19 +787,21 @@ static void runFinalize(dy_ctx * ctx, const dy_index * idx, dy_reads * reads, co
             const u32 dpThreads = 64;
             const size_t traceLds = (size_t)traceRows * dpThreads * 4;
             const u32 groupLds = groupDpLdsBytes(dpLen);
-            HIP_CHECK(hipStreamWaitEvent(ctx->side[2], ctx->evFork, 0));
+            // three chains: the thread-level aggregation on side[0], the alignment lists on side[1], the wavefront-level aggregation on the main
+            // stream itself (a fourth stream shared a hardware queue with another one — HIP deals its streams over four — and on reads with
+            // 1-3 % errors, where every chain is long, two of them ran one after the other: 568 us instead of 405)
             hipLaunchKernelGGL((k_finalize_small<3, u32>), dim3((u32)ctx->tune.dpSmallBlocks), dim3(dpThreads), traceLds, ctx->side[0], fa, ctx->smallList.as<u32>(), smallCount);
             hipLaunchKernelGGL(k_finalize_t<BlockGroup>, dim3(hugeBlocks), dim3(1024), 0, ctx->side[0], fa, blockMin + 1, 0xFFFFFFFFu, finWaves);
-            hipLaunchKernelGGL(k_finalize_t<WaveGroup>, dim3(finBlocks), dim3(256), 0, ctx->side[1], fa, 0u, blockMin, 0u);
-            if (splitWide) hipLaunchKernelGGL(k_finalize_small_group, dim3(1024), dim3(256), 16 * groupLds, ctx->side[1], fa, smallWideList, smallWideCount, groupLds);
-            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, ctx->side[2], fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount, dpWideList, dpWideCount);
-            if (splitWide) hipLaunchKernelGGL(k_align_group, dim3(1024), dim3(256), 16 * groupLds, ctx->side[2], fa, dpWideList, dpWideCount, groupLds);
-            hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, ctx->side[2], fa, ctx->dpList.as<u32>(), dpCount);
-            for (int q = 0; q < 3; ++q) HIP_CHECK(hipEventRecord(ctx->evJoin[q], ctx->side[q]));
+            hipLaunchKernelGGL(k_align_check, dim3(1024), dim3(256), 0, ctx->side[1], fa, ctx->alignList.as<u32>(), alignCount, ctx->dpList.as<u32>(), dpCount, dpWideList, dpWideCount);
+            if (splitWide) hipLaunchKernelGGL(k_align_group, dim3(1024), dim3(256), 16 * groupLds, ctx->side[1], fa, dpWideList, dpWideCount, groupLds);
+            hipLaunchKernelGGL((k_align_single<3, u32>), dim3((u32)ctx->tune.dpAlignBlocks), dim3(dpThreads), traceLds, ctx->side[1], fa, ctx->dpList.as<u32>(), dpCount);
+            for (int q = 0; q < 2; ++q) HIP_CHECK(hipEventRecord(ctx->evJoin[q], ctx->side[q]));
+            hipLaunchKernelGGL(k_finalize_t<WaveGroup>, dim3(finBlocks), dim3(256), 0, st, fa, 0u, blockMin, 0u);
+            if (splitWide) hipLaunchKernelGGL(k_finalize_small_group, dim3(1024), dim3(256), 16 * groupLds, st, fa, smallWideList, smallWideCount, groupLds);
             // (Measured and dropped: starting a deferred sweep of the NEXT batch here, on the main stream, beside the three chains — a few hundred
             // wavefronts that spend ~0.2 ms on per-wave latency.  5.099 vs 5.088 ms per step: the sweep's half a million workgroups win the
             // dispatch, the chains run in its tail like every other kernel queued beside a sweep.)
-            for (int q = 0; q < 3; ++q) HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[q], 0));
+            for (int q = 0; q < 2; ++q) HIP_CHECK(hipStreamWaitEvent(st, ctx->evJoin[q], 0));
         }
         else
         {
