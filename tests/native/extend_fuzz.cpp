@@ -23,7 +23,7 @@ static bool same(u8 a, u8 b) { return a == b && a < 4; }
 int main(int argc, char ** argv)
 {
     const long rounds = argc > 1 ? atol(argv[1]) : 400000;
-    std::mt19937_64 rng(777);
+    std::mt19937_64 rng(argc > 2 ? strtoull(argv[2], nullptr, 10) : 777ull);
     long closedLeft = 0, closedRight = 0, shiftedLeft = 0, shiftedRight = 0, refused = 0;
     const int PAD = 96;
     for (long it = 0; it < rounds; ++it)
